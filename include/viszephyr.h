@@ -1,0 +1,177 @@
+/*
+ * viszephyr.h - C ABI of libviszephyr_hip.so: the MI355X (gfx950) implementation of the
+ * Vision-Zephyr forward/generate hot path.
+ *
+ * The reference (baohuyvanba/Vision-Zephyr) is 100 % Python and has no FFI layer; its boundary
+ * for this path is the Python class API of
+ *     vis_zephyr/model/language_model/vis_zephyr.py:28-170   (VisZephyrForCausalLM.forward/generate)
+ *     vis_zephyr/model/vis_zephyr_arch.py:120-333            (encode_images, prepare_inputs_labels_for_multimodal)
+ * whose arithmetic it delegates to HF transformers / torch.nn.  This header is what a maintainer
+ * binds (ctypes stub in INTEGRATION.md) to replace that arithmetic: plain pointers and sizes, no
+ * torch types, int status codes, no exceptions across the boundary.  Every pointer named `d_*`
+ * is a DEVICE pointer borrowed for the duration of the call (weights: for the engine's lifetime);
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).  bf16 tensors are uint16_t.
+ *
+ * Two layers:
+ *   1. operator entry points  (vz_op_*): one hand-written kernel each; used by the parity tests
+ *      and by the engine itself.
+ *   2. engine entry points    (vz_engine_* / vz_clip_* / vz_qformer / vz_llm_*): own workspace and
+ *      the KV cache, sequence the kernels of one stage on the caller's stream.
+ */
+#ifndef VISZEPHYR_H
+#define VISZEPHYR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VZ_OK 0
+#define VZ_ERR_ARG 1          /* bad argument / unsupported shape  -> Python ValueError      */
+#define VZ_ERR_HIP 2          /* HIP runtime error                 -> Python RuntimeError    */
+#define VZ_ERR_STATE 3        /* call order / missing weights      -> Python RuntimeError    */
+#define VZ_ERR_UNSUPPORTED 4  /* reference-unreachable feature     -> NotImplementedError    */
+
+typedef void* vz_stream;
+typedef struct vz_engine vz_engine;
+
+/* last error message of the calling thread ("" if none) */
+const char* vz_last_error(void);
+/* ABI version; bumped on any signature change */
+int vz_abi_version(void);
+/* name of the code object's target ("gfx950") */
+const char* vz_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Operator entry points
+ * ------------------------------------------------------------------------------------------ */
+
+/* epilogue activation ids */
+#define VZ_ACT_NONE 0
+#define VZ_ACT_QUICK_GELU 1   /* x*sigmoid(1.702x)  hf:activations.py:117-123 (CLIPMLP)            */
+#define VZ_ACT_GELU_ERF 2     /* exact GELU         torch nn.GELU (Q-Former FFN, ref builder.py:29) */
+#define VZ_ACT_SWIGLU 3       /* silu(gate)*up, W rows interleaved [16 gate | 16 up]; out width N/2
+                                 hf:models/mistral/modeling_mistral.py:35-48 (MistralMLP)          */
+
+/* C[M,N'] = epi(A[M,K] . W[N,K]^T): every nn.Linear on the path
+ * (hf:models/clip/modeling_clip.py:280-350, hf:models/mistral/modeling_mistral.py:35-48,122-178,
+ *  torch MultiheadAttention in/out projections ref:vis_zephyr/model/multimodal_projector/builder.py:16-32).
+ * bf16 A/W, fp32 accumulate (MFMA), bias fp32 [N] or NULL, residual bf16 [M,ldr] or NULL (may alias C),
+ * out bf16 (out_fp32=0) or fp32.  K % 64 == 0.  M <= 8 routes to the weight-streaming GEMV. */
+int vz_op_linear(const void* d_A, int lda, const void* d_W, int ldw, void* d_C, int ldc,
+                 int M, int N, int K, const float* d_bias, const void* d_residual, int ldr,
+                 int act, int out_fp32, vz_stream stream);
+/* same contract, forcing one implementation (tests): impl 0 = MFMA tile GEMM, 1 = GEMV */
+int vz_op_linear_impl(int impl, const void* d_A, int lda, const void* d_W, int ldw, void* d_C, int ldc,
+                      int M, int N, int K, const float* d_bias, const void* d_residual, int ldr,
+                      int act, int out_fp32, vz_stream stream);
+
+/* y = LayerNorm(x) (torch.nn.LayerNorm; CLIP hf:...modeling_clip.py:353-384, Q-Former builder.py:14-27,68-70) */
+int vz_op_layernorm(const void* d_x, int ldx, void* d_y, int ldy, const float* d_w, const float* d_b,
+                    int rows, int cols, float eps, vz_stream stream);
+/* y = w * x * rsqrt(mean(x^2)+eps)  (MistralRMSNorm hf:models/mistral/modeling_mistral.py:182-199) */
+int vz_op_rmsnorm(const void* d_x, int ldx, void* d_y, int ldy, const float* d_w,
+                  int rows, int cols, float eps, vz_stream stream);
+
+/* softmax(scale * Q K^T [+causal/window mask]) V, fp32 softmax, GQA by head grouping
+ * (hf:models/clip/modeling_clip.py:259-277; hf:models/mistral/modeling_mistral.py:84-119;
+ *  torch MultiheadAttention).  Element strides (batch, seq, head) per tensor; head_dim in {64,128,512}.
+ * causal: query i of batch b sits at absolute position q_pos0 + i and sees keys j <= position,
+ * j > position - window (window <= 0: unlimited).  d_kv_len (int32 [B]) or NULL (= Sk) bounds the
+ * valid keys of each batch row. */
+int vz_op_attention(const void* d_q, const void* d_k, const void* d_v, void* d_o,
+                    int B, int Sq, int Sk, int Hq, int Hkv, int head_dim,
+                    long q_bs, long q_ss, long q_hs, long k_bs, long k_ss, long k_hs,
+                    long v_bs, long v_ss, long v_hs, long o_bs, long o_ss, long o_hs,
+                    float scale, int causal, int q_pos0, int window, const int* d_kv_len,
+                    vz_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Engine
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vz_config {
+    /* Zephyr-7B-beta (ref:checkpoints/vis-zephyr-7b-v1-pretrain/config.json:10-38) */
+    int hidden, inter, n_layers, n_heads, n_kv_heads, head_dim, vocab;
+    float rms_eps, rope_theta;
+    int sliding_window;
+    /* CLIP ViT-L/14-336 (ref:vis_zephyr/model/vision_encoder/vision_encoder.py:21) */
+    int clip_hidden, clip_inter, clip_layers, clip_heads, clip_image, clip_patch;
+    float clip_eps;
+    /* Q-Former (ref:vis_zephyr/model/multimodal_projector/builder.py:49-70) */
+    int qf_queries, qf_blocks, qf_heads, qf_kv_dim;
+    float qf_eps;
+    /* fusion (ref:vis_zephyr/model/vision_encoder/vision_encoder.py:63-64) */
+    int fusion_groups, fusion_layers_per_group;
+    /* capacity */
+    int max_batch;        /* KV-cache slots                                  */
+    int max_ctx;          /* tokens per slot                                 */
+    int max_tiles;        /* tiles per vz_clip_fused_features / vz_qformer   */
+    int max_text;         /* Lmax of the Q-Former text conditioning          */
+    /* tensor parallelism over RCCL (1 = single GPU) */
+    int tp_size, tp_rank;
+} vz_config;
+
+int vz_engine_create(const vz_config* cfg, vz_engine** out);
+int vz_engine_destroy(vz_engine* e);
+
+/* Register one weight under its engine name (see vz_hip/weights.py for the packing from the
+ * reference's state-dict keys).  dtype: 0 = bf16, 1 = fp32.  The pointer is borrowed until destroy. */
+int vz_engine_set_weight(vz_engine* e, const char* name, const void* d_ptr, int dtype, long n_elems);
+/* check that every weight the configuration needs has been registered */
+int vz_engine_finalize(vz_engine* e);
+/* fp32 rotary tables [max_pos, head_dim/2] (rotate-half convention, hf:...modeling_mistral.py:51-81,262-317) */
+int vz_engine_set_rope(vz_engine* e, const float* d_cos, const float* d_sin, int max_pos);
+
+/* a8-a10: CLIPVisionTower.forward + feature_select + fusion
+ * (ref:vis_zephyr/model/vision_encoder/vision_encoder.py:58-117, gating_fusion.py:22-50).
+ * d_images bf16 [T,3,336,336] -> d_out bf16 [T,576,5*clip_hidden].
+ * d_hidden_dbg: NULL, or bf16 [(clip_layers+1),T,577,clip_hidden] receiving every hidden state (tests). */
+int vz_clip_fused_features(vz_engine* e, const void* d_images, int T, void* d_out, void* d_hidden_dbg,
+                           vz_stream stream);
+
+/* a11: QFormer.forward (ref:vis_zephyr/model/multimodal_projector/builder.py:72-92).
+ * d_feats bf16 [T,576,qf_kv_dim]; text conditioning per SAMPLE: d_text bf16 [n_samples,Lmax,hidden]
+ * (rows past a sample's own length are the zero padding of ref:vis_zephyr/model/vis_zephyr_arch.py:178-189),
+ * h_tile_sample[T] maps each tile to its sample (the reference expands the same text to every tile of a
+ * sample, vis_zephyr_arch.py:174).  Lmax = 0: no text.  d_out bf16 [T,32,hidden]. */
+int vz_qformer(vz_engine* e, const void* d_feats, int T, const void* d_text, int n_samples, int Lmax,
+               const int* h_tile_sample, void* d_out, vz_stream stream);
+
+/* a6/a7 data movement: out[r,:] = kind[r]==0 ? embed_tokens[idx[r]] : kind[r]==1 ? d_visual[idx[r]] : 0
+ * (the row map itself is host index logic, ref:vis_zephyr/model/vis_zephyr_arch.py:214-333,476-530). */
+int vz_embed_splice(vz_engine* e, const int* d_kind, const int* d_idx, int rows, const void* d_visual,
+                    void* d_out, vz_stream stream);
+
+/* a12 prefill: MistralForCausalLM.forward on inputs_embeds (hf:models/mistral/modeling_mistral.py:340-466).
+ * d_embeds bf16 [B,S,hidden] right-padded, h_seqlens[B] valid lengths, d_pos int32 [B,S] position ids.
+ * Fills KV slots 0..B-1 from position 0.  d_logits_all: NULL or fp32 [B,S,vocab] (forward() computes all
+ * positions); d_logits_last: NULL or fp32 [B,vocab] (row seqlen-1 of each sample; what generate needs). */
+int vz_llm_prefill(vz_engine* e, const void* d_embeds, int B, int S, const int* h_seqlens, const int* d_pos,
+                   float* d_logits_all, float* d_logits_last, vz_stream stream);
+
+/* a13 greedy decode.  vz_llm_decode_begin arms the device-side state after a prefill: the first input
+ * token of every slot (d_first_ids int32 [B]), next position ids and context lengths (host int [B]).
+ * vz_llm_decode_steps enqueues n steps with no host synchronisation: every step embeds the current token,
+ * runs the 32 layers against the cache, takes argmax of the fp32 logits (first maximal index, as
+ * torch.argmax) and feeds it to the next step.  d_out_ids int32 [B, n] receives the n new tokens;
+ * d_logits_dbg NULL or fp32 [n,B,vocab]. */
+int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, const int* h_next_pos, const int* h_ctx_len,
+                        vz_stream stream);
+int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d_logits_dbg, vz_stream stream);
+
+/* argmax over fp32 logits rows: ids int32 [rows] (first maximal index) */
+int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_stream stream);
+
+/* per-kernel-class timing of the engine's launches with HIP events on the launch stream (bench.py's roofline
+ * leg).  enable=1 disables graph replay and brackets every launch of class `klass` with events.
+ * classes: 0 gemm(mfma) 1 gemv 2 attention 3 attn_decode 4 norm 5 other */
+int vz_prof_enable(vz_engine* e, int enable, int klass);
+/* synchronises the events; returns launches counted and their total milliseconds */
+int vz_prof_read(vz_engine* e, long* n_launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISZEPHYR_H */

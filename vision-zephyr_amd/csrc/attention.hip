@@ -1,0 +1,343 @@
+// Attention kernels of the Vision-Zephyr hot path (gfx950).
+//
+// flash_attn_kernel<HD,KT>: softmax(scale*Q K^T + mask) V without materialising the scores, for
+//   * CLIP self-attention   577x577, 16 heads x 64, no mask      hf:models/clip/modeling_clip.py:259-335
+//   * Q-Former self / cross 32 x (32..1920 | 576), 8 heads x 512 torch.nn.MultiheadAttention,
+//                                                                ref:vis_zephyr/model/multimodal_projector/builder.py:16-25,34-39
+//   * Zephyr prefill        causal + sliding window, GQA 32q/8kv x 128
+//                                                                hf:models/mistral/modeling_mistral.py:84-119,139-178
+// One workgroup = 4 waves x 16 query rows.  Scores are computed TRANSPOSED (S^T = K Q^T with
+// v_mfma_f32_16x16x32_bf16: keys on the accumulator rows, the query on the lane), so that
+//   - the row statistics of a query live in one lane column (reduce over 4 lane groups: 2 shuffles),
+//   - exp(S^T) packed to bf16 is already the B operand of O^T += V^T P^T (no LDS round trip for P),
+//   - the O^T accumulators of a lane all belong to its own query: the online-softmax rescale is
+//     lane-local.
+// K tiles are staged row-major in LDS (16-byte reads feed the MFMA A operand directly); V tiles are
+// staged TRANSPOSED ([d][key], two keys packed per 32-bit LDS write) so the V^T A operand is two
+// 8-byte reads.  GQA never materialises repeat_kv: query head h reads KV head h / (Hq/Hkv).
+// fp32 softmax with running max / normaliser; P is rounded to bf16 for the MFMA, the normaliser
+// is summed from the unrounded exponentials (what oracle/vz_oracle.py::_attention mirrors).
+//
+// attn_decode_kernel + attn_decode_combine: one query token against the KV cache (HBM-bound,
+// split over the context so that B*Hq*nsplit workgroups stream the cache), lengths read from
+// device memory so that a captured hipGraph replays for every step.
+#include "vz_common.h"
+
+namespace {
+
+struct FlashParams {
+    const bf16_t *q, *k, *v;
+    bf16_t* o;
+    int B, Sq, Sk, Hq, Hkv;
+    long q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ss, o_hs;
+    float scale;
+    int causal, q_pos0, window;
+    const int* kv_len;
+};
+
+template <int HD, int KT>
+__global__ __launch_bounds__(256, 1) void flash_attn_kernel(FlashParams p) {
+    constexpr int KS_STRIDE = HD * 2 + 16;   // bytes per K row in LDS (+16: spreads the 16 rows of a fragment read)
+    constexpr int VT_STRIDE = KT * 2 + 8;    // bytes per V^T row (d) in LDS
+    constexpr int NT = KT / 16;              // 16-key score tiles per KV tile
+    constexpr int DS = HD / 32;              // k-steps of the QK^T contraction
+    constexpr int DT = HD / 16;              // 16-wide d tiles of O^T
+    constexpr int CPK = HD / 8;              // 16-byte chunks per K/V row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vt = smem + KT * KS_STRIDE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int hk = h / (p.Hq / p.Hkv);
+    const int kv_len = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+
+    // ---- this lane's query row (B operand of S^T = K Q^T): Q[q][ds*32 + 8g .. +7] ----
+    int qrow = q0 + wave * 16 + c;
+    const bool q_valid = qrow < p.Sq;
+    if (!q_valid) qrow = p.Sq - 1;
+    const bf16_t* qp = p.q + (size_t)b * p.q_bs + (size_t)qrow * p.q_ss + (size_t)h * p.q_hs;
+    bf16x8 qf[DS];
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) qf[ds] = *(const bf16x8*)(qp + ds * 32 + g * 8);
+    const int qpos = p.q_pos0 + qrow;
+
+    f32x4 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // key range needed by this workgroup's 64 query rows
+    int k_end = kv_len;
+    int k_begin = 0;
+    if (p.causal) {
+        const int last_q = min(q0 + 63, p.Sq - 1) + p.q_pos0;
+        k_end = min(k_end, last_q + 1);
+        if (p.window > 0) k_begin = max(0, q0 + p.q_pos0 - p.window + 1);
+    }
+    const int t_begin = k_begin / KT, t_end = (k_end + KT - 1) / KT;
+
+    const bf16_t* kbase = p.k + (size_t)b * p.k_bs + (size_t)hk * p.k_hs;
+    const bf16_t* vbase = p.v + (size_t)b * p.v_bs + (size_t)hk * p.v_hs;
+    const int last_key = kv_len > 0 ? kv_len - 1 : 0;
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int key0 = t * KT;
+        __syncthreads();  // every wave has finished reading the previous tile
+        // ---- stage K row-major ----
+#pragma unroll
+        for (int i = 0; i < (KT * CPK) / 256; ++i) {
+            const int ch = i * 256 + tid;
+            const int kr = ch / CPK, dc = ch % CPK;
+            const int krow = min(key0 + kr, last_key);
+            const uint4 val = *(const uint4*)(kbase + (size_t)krow * p.k_ss + dc * 8);
+            *(uint4*)(Ks + kr * KS_STRIDE + dc * 16) = val;
+        }
+        // ---- stage V transposed: unit = (key pair, 8-wide d chunk) -> 8 packed 32-bit LDS writes ----
+#pragma unroll
+        for (int i = 0; i < ((KT / 2) * CPK) / 256; ++i) {
+            const int u = i * 256 + tid;
+            const int kp = u % (KT / 2), dc = u / (KT / 2);
+            const int r0 = min(key0 + 2 * kp, last_key), r1 = min(key0 + 2 * kp + 1, last_key);
+            const u16x8 a = *(const u16x8*)(vbase + (size_t)r0 * p.v_ss + dc * 8);
+            const u16x8 bb = *(const u16x8*)(vbase + (size_t)r1 * p.v_ss + dc * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *(unsigned*)(Vt + (dc * 8 + j) * VT_STRIDE + kp * 4) = (unsigned)a[j] | ((unsigned)bb[j] << 16);
+        }
+        __syncthreads();
+
+        // ---- S^T tiles: sacc[nt][r] = S[key = key0 + nt*16 + 4g + r][q = this lane's query] ----
+        f32x4 sacc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            sacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) {
+                const bf16x8 kf = *(const bf16x8*)(Ks + (nt * 16 + c) * KS_STRIDE + ds * 64 + g * 16);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ds], sacc[nt], 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax (per lane column) ----
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kidx = key0 + nt * 16 + 4 * g + r;
+                bool ok = kidx < kv_len;
+                if (p.causal) ok = ok && kidx <= qpos && (p.window <= 0 || kidx > qpos - p.window);
+                const float s = ok ? sacc[nt][r] * p.scale : -INFINITY;
+                sacc[nt][r] = s;
+                m_tile = fmaxf(m_tile, s);
+            }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+        const float m_new = fmaxf(m_run, m_tile);
+        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_safe);  // m_run = -inf -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(sacc[nt][r] - m_safe);
+                sacc[nt][r] = e;
+                psum += e;
+            }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha;
+        }
+        // ---- O^T += V^T P^T.  k-slot j of lane group g in k-step s is key  (2s + (j>>2))*16 + 4g + (j&3) ----
+#pragma unroll
+        for (int s = 0; s < NT / 2; ++s) {
+            bf16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (__bf16)sacc[2 * s][r];
+                pf[4 + r] = (__bf16)sacc[2 * s + 1][r];
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const char* vrow = Vt + (dt * 16 + c) * VT_STRIDE + g * 8;
+                const bf16x4 v0 = *(const bf16x4*)(vrow + (2 * s) * 32);
+                const bf16x4 v1 = *(const bf16x4*)(vrow + (2 * s + 1) * 32);
+                const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: oacc[dt][r] = O[q = this lane's query][d = dt*16 + 4g + r] ----
+    if (q_valid) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        bf16_t* op = p.o + (size_t)b * p.o_bs + (size_t)qrow * p.o_ss + (size_t)h * p.o_hs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            uint2 pk;
+            pk.x = pack_bf16x2(oacc[dt][0] * inv, oacc[dt][1] * inv);
+            pk.y = pack_bf16x2(oacc[dt][2] * inv, oacc[dt][3] * inv);
+            *(uint2*)(op + dt * 16 + 4 * g) = pk;
+        }
+    }
+}
+
+template <int HD, int KT>
+int launch_flash(const FlashParams& p, hipStream_t s) {
+    constexpr int LDS = KT * (HD * 2 + 16) + HD * (KT * 2 + 8);
+    static bool attr = false;
+    if (!attr) {
+        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn_kernel<HD, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    dim3 grid((p.Sq + 63) / 64, p.Hq, p.B);
+    hipLaunchKernelGGL((flash_attn_kernel<HD, KT>), grid, dim3(256), LDS, s, p);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode attention
+// ------------------------------------------------------------------------------------------------
+struct DecodeParams {
+    const bf16_t *q, *kc, *vc;
+    bf16_t* o;
+    float* part;
+    int B, Hq, Hkv, max_ctx, nsplit, window;
+    float scale;
+    const int* ctx_len;
+};
+
+constexpr int DEC_D = 128;
+constexpr int DEC_MAX_CHUNK = 512;  // keys per split handled through LDS scores
+
+// grid (nsplit, Hq, B).  part layout per (b,h,split): [m, l, o[128]]
+__global__ __launch_bounds__(256) void attn_decode_kernel(DecodeParams p) {
+    __shared__ float sc[DEC_MAX_CHUNK];
+    __shared__ float red[8];
+    __shared__ float obuf[2][DEC_D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int hk = h / (p.Hq / p.Hkv);
+    const int ctx = p.ctx_len[b];
+    int lo_vis = 0;
+    if (p.window > 0) lo_vis = max(0, ctx - p.window);  // the query sits at position ctx-1
+    const int span = ctx - lo_vis;
+    const int chunk = (span + p.nsplit - 1) / p.nsplit;
+    const int k0 = lo_vis + split * chunk;
+    const int k1 = min(ctx, k0 + chunk);
+    float* po = p.part + (((size_t)b * p.Hq + h) * p.nsplit + split) * (DEC_D + 2);
+    if (k0 >= k1) {  // empty split (uniform over the block)
+        if (tid == 0) { po[0] = -INFINITY; po[1] = 0.f; }
+        if (tid < DEC_D) po[2 + tid] = 0.f;
+        return;
+    }
+    const bf16_t* kb = p.kc + ((size_t)b * p.Hkv + hk) * (size_t)p.max_ctx * DEC_D;
+    const bf16_t* vb = p.vc + ((size_t)b * p.Hkv + hk) * (size_t)p.max_ctx * DEC_D;
+    // q fragment: 16 lanes cover one key row of 128 d, 8 d each
+    const int sub = lane & 15, grp = lane >> 4;
+    const u16x8 qv = *(const u16x8*)(p.q + ((size_t)b * p.Hq + h) * DEC_D + sub * 8);
+    float qf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[j] = bf16_to_f32(qv[j]);
+
+    float m_run = -INFINITY, l_run = 0.f;
+    float oacc = 0.f;  // thread (d = tid & 127, half = tid >> 7)
+    const int d = tid & 127, half = tid >> 7;
+    for (int c0 = k0; c0 < k1; c0 += DEC_MAX_CHUNK) {
+        const int n = min(DEC_MAX_CHUNK, k1 - c0);
+        __syncthreads();
+        // scores: each 16-lane group takes one key per pass; 16 keys per block pass
+        for (int kk = wave * 4 + grp; kk < n; kk += 16) {
+            const u16x8 kv = *(const u16x8*)(kb + (size_t)(c0 + kk) * DEC_D + sub * 8);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += qf[j] * bf16_to_f32(kv[j]);
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+            if (sub == 0) sc[kk] = s * p.scale;
+        }
+        __syncthreads();
+        float mx = -INFINITY;
+        for (int kk = tid; kk < n; kk += 256) mx = fmaxf(mx, sc[kk]);
+        mx = wave_max(mx);
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        const float m_new = fmaxf(m_run, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        float ps = 0.f;
+        for (int kk = tid; kk < n; kk += 256) { const float e = __expf(sc[kk] - m_new); sc[kk] = e; ps += e; }
+        ps = wave_sum(ps);
+        if (lane == 0) red[4 + wave] = ps;
+        __syncthreads();
+        const float alpha = __expf(m_run - m_new);
+        l_run = l_run * alpha + red[4] + red[5] + red[6] + red[7];
+        m_run = m_new;
+        float a = 0.f;
+        for (int kk = half; kk < n; kk += 2) a += sc[kk] * bf16_to_f32(vb[(size_t)(c0 + kk) * DEC_D + d]);
+        oacc = oacc * alpha + a;
+    }
+    obuf[half][d] = oacc;
+    __syncthreads();
+    if (tid < DEC_D) po[2 + tid] = obuf[0][tid] + obuf[1][tid];
+    if (tid == 0) { po[0] = m_run; po[1] = l_run; }
+}
+
+// grid (Hq, B), 128 threads: merge the nsplit partials
+__global__ __launch_bounds__(128) void attn_decode_combine(const float* __restrict__ part, bf16_t* __restrict__ o, int Hq, int nsplit) {
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const float* pp = part + ((size_t)b * Hq + h) * nsplit * (DEC_D + 2);
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, pp[s * (DEC_D + 2)]);
+    float l = 0.f, acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float ms = pp[s * (DEC_D + 2)];
+        const float w = ms == -INFINITY ? 0.f : __expf(ms - m);
+        l += w * pp[s * (DEC_D + 2) + 1];
+        acc += w * pp[s * (DEC_D + 2) + 2 + d];
+    }
+    o[((size_t)b * Hq + h) * DEC_D + d] = f32_to_bf16(l > 0.f ? acc / l : 0.f);
+}
+
+}  // namespace
+
+int vz_launch_attention(const AttnArgs& a, hipStream_t s) {
+    VZ_CHECK_ARG(a.q && a.k && a.v && a.o, "attention: null pointer");
+    VZ_CHECK_ARG(a.B > 0 && a.Sq > 0 && a.Sk > 0 && a.Hq > 0 && a.Hkv > 0 && a.Hq % a.Hkv == 0,
+                 "attention: bad shape B=%d Sq=%d Sk=%d Hq=%d Hkv=%d", a.B, a.Sq, a.Sk, a.Hq, a.Hkv);
+    VZ_CHECK_ARG(a.Hq <= 65535 && a.B <= 65535, "attention: grid too large");
+    const long strides[] = {a.q_bs, a.q_ss, a.q_hs, a.k_bs, a.k_ss, a.k_hs, a.v_bs, a.v_ss, a.v_hs, a.o_bs, a.o_ss, a.o_hs};
+    for (long st : strides) VZ_CHECK_ARG(st % 8 == 0, "attention: strides must be multiples of 8 elements");
+    VZ_CHECK_ARG(((uintptr_t)a.q & 15) == 0 && ((uintptr_t)a.k & 15) == 0 && ((uintptr_t)a.v & 15) == 0 &&
+                     ((uintptr_t)a.o & 15) == 0, "attention: pointers must be 16-byte aligned");
+    FlashParams p;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o;
+    p.B = a.B; p.Sq = a.Sq; p.Sk = a.Sk; p.Hq = a.Hq; p.Hkv = a.Hkv;
+    p.q_bs = a.q_bs; p.q_ss = a.q_ss; p.q_hs = a.q_hs; p.k_bs = a.k_bs; p.k_ss = a.k_ss; p.k_hs = a.k_hs;
+    p.v_bs = a.v_bs; p.v_ss = a.v_ss; p.v_hs = a.v_hs; p.o_bs = a.o_bs; p.o_ss = a.o_ss; p.o_hs = a.o_hs;
+    p.scale = a.scale; p.causal = a.causal; p.q_pos0 = a.q_pos0; p.window = a.window; p.kv_len = a.kv_len;
+    switch (a.head_dim) {
+        case 64: return launch_flash<64, 64>(p, s);
+        case 128: return launch_flash<128, 64>(p, s);
+        case 512: return launch_flash<512, 32>(p, s);
+        default: vz_set_error("attention: head_dim %d unsupported (64, 128, 512)", a.head_dim); return VZ_ERR_ARG;
+    }
+}
+
+int vz_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
+    VZ_CHECK_ARG(a.D == DEC_D, "attn_decode: head_dim %d unsupported (128)", a.D);
+    VZ_CHECK_ARG(a.nsplit >= 1 && a.nsplit <= 64 && a.Hq % a.Hkv == 0, "attn_decode: bad split/heads");
+    DecodeParams p;
+    p.q = a.q; p.kc = a.kc; p.vc = a.vc; p.o = a.o; p.part = a.part;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.max_ctx = a.max_ctx; p.nsplit = a.nsplit; p.window = a.window;
+    p.scale = a.scale; p.ctx_len = a.ctx_len;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(a.nsplit, a.Hq, a.B), dim3(256), 0, s, p);
+    VZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_decode_combine, dim3(a.Hq, a.B), dim3(128), 0, s, (const float*)a.part, a.o, a.Hq, a.nsplit);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}

@@ -1,0 +1,384 @@
+// Linear layers of the Vision-Zephyr hot path on gfx950:  C[M,N'] = epi(A[M,K] . W[N,K]^T)
+//
+//   * gemm_bf16_kernel : 128x128x64 MFMA tile GEMM (v_mfma_f32_16x16x32_bf16), operands staged
+//     global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4) into a lane-linear image whose
+//     XOR swizzle is applied on the SOURCE address and again on the ds_read_b128 (conflict-free
+//     for the 16-row fragment reads), double-buffered, XCD-aware tile order.  Used for every
+//     M > 8 product: CLIP QKV/out/MLP, Q-Former projections, Zephyr prefill QKV/O/gate-up/down,
+//     lm_head over all positions.
+//   * gemv_bf16_kernel : weight-streaming GEMV for M <= 8 (decode): each wave streams two weight
+//     rows with 16-byte loads straight to VGPRs (no LDS round trip for data read once), x staged
+//     once per block in LDS, optional fused RMSNorm prologue, v_dot2c_f32_bf16 accumulate.
+//
+// Both take W as the reference stores it ([out_features, in_features], K contiguous), so no
+// transposed copy of the 7.2 B parameters is ever made.  Epilogues (bias, quick_gelu, erf-GELU,
+// SwiGLU pair, residual add, bf16/fp32 out) run on the fp32 accumulators before the single
+// rounding to bf16 - the rounding points the bf16 oracle mirrors (oracle/vz_oracle.py).
+//
+// Semantics: hf:models/clip/modeling_clip.py:280-350, hf:models/mistral/modeling_mistral.py:35-48,
+// 122-178,450-453, torch.nn.MultiheadAttention projections (ref:vis_zephyr/model/multimodal_projector/builder.py:16-32).
+#include "vz_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;      // A + W
+constexpr int GEMM_LDS = 2 * BUF_BYTES;        // double buffer: 64 KiB -> 2 workgroups / CU
+
+struct GemmParams {
+    const bf16_t* A; const bf16_t* W; void* C;
+    const float* bias; const bf16_t* residual;
+    int M, N, K, lda, ldw, ldc, ldr;
+    int act, out_fp32, tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
+    // LDS destination = wave-uniform base + lane*16 (hardware); source address is per lane
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == VZ_ACT_QUICK_GELU) return act_quick_gelu(v);
+    if (act == VZ_ACT_GELU_ERF) return act_gelu_erf(v);
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves, 64(m) x 64(n) each
+
+    // XCD-aware, bijective tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a
+    // contiguous run of tiles; inside a run tiles walk M first, i.e. neighbours share one W panel.
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int bn = tile / p.tiles_m, bm = tile - bn * p.tiles_m;
+
+    // ---- staging addresses: 1024 16-byte chunks per operand tile, 4 per thread ----
+    const char* ga[4];
+    const char* gw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = i * 256 + tid;
+        const int row = ch >> 3, c = ch & 7;
+        const int gc = c ^ (row & 7);  // swizzle on the source; the LDS image stays lane-linear
+        int arow = bm * BM + row; arow = arow < p.M ? arow : p.M - 1;
+        int wrow = bn * BN + row; wrow = wrow < p.N ? wrow : p.N - 1;
+        ga[i] = (const char*)p.A + ((size_t)arow * p.lda) * 2 + gc * 16;
+        gw[i] = (const char*)p.W + ((size_t)wrow * p.ldw) * 2 + gc * 16;
+    }
+    const int wave_chunk = wave * 64 * 16;
+
+    // ---- fragment read addresses (16x16x32: lane holds row lane&15, k = 8*(lane>>4)+j) ----
+    const int frow = lane & 15, g = lane >> 4;
+    const int koff0 = ((g ^ (lane & 7)) << 4);  // k-step 0; k-step 1 = koff0 ^ 64
+    const int a_off = (wm * 64 + frow) * 128;
+    const int w_off = TILE_BYTES + (wn * 64 + frow) * 128;
+
+    f32x4 acc[4][4];  // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    auto stage = [&](int buf, int kt) {
+        char* la = smem + buf * BUF_BYTES + wave_chunk;
+        char* lw = la + TILE_BYTES;
+        const int kb = kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(ga[i] + kb, la + i * 4096);
+            glds16(gw[i] + kb, lw + i * 4096);
+        }
+    };
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* base = smem + cur * BUF_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ko = koff0 ^ (ks * 64);
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const bf16x8*)(base + a_off + t * 2048 + ko);
+                wf[t] = *(const bf16x8*)(base + w_off + t * 2048 + ko);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: acc[nt][mt][j] = C[m = .. + mt*16 + (lane&15)][n = .. + nt*16 + 4*(lane>>4) + j] ----
+    const int m_base = bm * BM + wm * 64 + frow;
+    const int n_base = bn * BN + wn * 64 + g * 4;
+    const bool swiglu = p.act == VZ_ACT_SWIGLU;
+    const int n_out_total = swiglu ? p.N / 2 : p.N;
+    const bool vec_ok = (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m_base + mt * 16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            float v[4];
+            int n0;
+            if (swiglu) {
+                if (nt & 1) continue;
+                // weight rows are interleaved [16 gate | 16 up]: tile nt = gate, nt+1 = up, same lane slots
+                n0 = ((bn * BN + wn * 64) >> 1) + (nt >> 1) * 16 + g * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_silu(acc[nt][mt][j]) * acc[nt + 1][mt][j];
+            } else {
+                n0 = n_base + nt * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = acc[nt][mt][j];
+                    if (p.bias && n0 + j < p.N) t += p.bias[n0 + j];
+                    v[j] = apply_act(t, p.act);
+                }
+            }
+            if (n0 >= n_out_total) continue;
+            if (vec_ok && n0 + 3 < n_out_total) {
+                if (p.residual) {
+                    const u16x4 rr = *(const u16x4*)(p.residual + (size_t)m * p.ldr + n0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += bf16_to_f32(rr[j]);
+                }
+                if (p.out_fp32) {
+                    *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n0) = (f32x4){v[0], v[1], v[2], v[3]};
+                } else {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n0) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n0 + j >= n_out_total) break;
+                    float t = v[j];
+                    if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + n0 + j]);
+                    if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + n0 + j] = t;
+                    else ((bf16_t*)p.C)[(size_t)m * p.ldc + n0 + j] = f32_to_bf16(t);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMV (M <= 8)
+// ------------------------------------------------------------------------------------------------
+struct GemvParams {
+    const bf16_t* A; const bf16_t* W; void* C;
+    const float* bias; const bf16_t* residual; const float* norm_w;
+    int M, N, K, lda, ldw, ldc, ldr;
+    int act, out_fp32, units;
+    float norm_eps;
+};
+
+__device__ __forceinline__ float dot8(const uint4& w, const uint4& x, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.x), __builtin_bit_cast(bf16x2, x.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.y), __builtin_bit_cast(bf16x2, x.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.z), __builtin_bit_cast(bf16x2, x.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.w), __builtin_bit_cast(bf16x2, x.w), acc, false);
+    return acc;
+}
+
+template <int MB>
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // xs[MB][K] bf16, then 16 floats of scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K;
+    float* red = (float*)(smem + (size_t)MB * K * 2);
+
+    // ---- prologue: x (optionally RMS-normalised) -> LDS as bf16 ----
+    for (int m = 0; m < MB; ++m) {
+        bf16_t* xs = (bf16_t*)smem + (size_t)m * K;
+        if (m >= p.M) {
+            for (int k = tid * 8; k < K; k += 256 * 8) *(uint4*)(xs + k) = make_uint4(0, 0, 0, 0);
+            continue;
+        }
+        const bf16_t* x = p.A + (size_t)m * p.lda;
+        if (p.norm_w) {
+            float ss = 0.f;
+            for (int k = tid * 8; k < K; k += 256 * 8) {
+                const u16x8 v = *(const u16x8*)(x + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(v[j]); ss += f * f; }
+            }
+            ss = wave_sum(ss);
+            __syncthreads();
+            if (lane == 0) red[wave] = ss;
+            __syncthreads();
+            const float tot = red[0] + red[1] + red[2] + red[3];
+            const float rstd = rsqrtf(tot / (float)K + p.norm_eps);
+            for (int k = tid * 8; k < K; k += 256 * 8) {
+                const u16x8 v = *(const u16x8*)(x + k);
+                const f32x4 w0 = *(const f32x4*)(p.norm_w + k), w1 = *(const f32x4*)(p.norm_w + k + 4);
+                u16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float wj = j < 4 ? w0[j] : w1[j - 4];
+                    o[j] = f32_to_bf16(wj * (bf16_to_f32(v[j]) * rstd));
+                }
+                *(u16x8*)(xs + k) = o;
+            }
+        } else {
+            for (int k = tid * 8; k < K; k += 256 * 8) *(uint4*)(xs + k) = *(const uint4*)(x + k);
+        }
+    }
+    __syncthreads();
+
+    const bool swiglu = p.act == VZ_ACT_SWIGLU;
+    const int nchunk = K >> 9;  // 512 elements (1 KiB) per wave-instruction
+    for (int u = blockIdx.x * 4 + wave; u < p.units; u += gridDim.x * 4) {
+        int r0, r1;
+        if (swiglu) { r0 = (u >> 4) * 32 + (u & 15); r1 = r0 + 16; }
+        else { r0 = 2 * u; r1 = r0 + 1 < p.N ? r0 + 1 : r0; }
+        const bf16_t* w0p = p.W + (size_t)r0 * p.ldw + lane * 8;
+        const bf16_t* w1p = p.W + (size_t)r1 * p.ldw + lane * 8;
+        float a0[MB], a1[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) { a0[m] = 0.f; a1[m] = 0.f; }
+#pragma unroll 4
+        for (int c = 0; c < nchunk; ++c) {
+            const uint4 w0 = *(const uint4*)(w0p + c * 512);
+            const uint4 w1 = *(const uint4*)(w1p + c * 512);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const uint4 xv = *(const uint4*)((const bf16_t*)smem + (size_t)m * K + c * 512 + lane * 8);
+                a0[m] = dot8(w0, xv, a0[m]);
+                a1[m] = dot8(w1, xv, a1[m]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) { a0[m] = wave_sum(a0[m]); a1[m] = wave_sum(a1[m]); }
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (m >= p.M) break;
+                if (swiglu) {
+                    float t = act_silu(a0[m]) * a1[m];
+                    if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + u]);
+                    if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + u] = t;
+                    else ((bf16_t*)p.C)[(size_t)m * p.ldc + u] = f32_to_bf16(t);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int n = 2 * u + h;
+                        if (n >= p.N) break;
+                        float t = h ? a1[m] : a0[m];
+                        if (p.bias) t += p.bias[n];
+                        t = apply_act(t, p.act);
+                        if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + n]);
+                        if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + n] = t;
+                        else ((bf16_t*)p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(t);
+                    }
+                }
+            }
+        }
+    }
+}
+
+int check_common(const LinearArgs& a) {
+    VZ_CHECK_ARG(a.A && a.W && a.C, "linear: null pointer");
+    VZ_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "linear: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    VZ_CHECK_ARG(a.K % 64 == 0, "linear: K=%d must be a multiple of 64", a.K);
+    VZ_CHECK_ARG(a.lda >= a.K && a.ldw >= a.K && (a.lda % 8) == 0 && (a.ldw % 8) == 0,
+                 "linear: lda=%d ldw=%d must be >= K and multiples of 8", a.lda, a.ldw);
+    VZ_CHECK_ARG(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 && ((uintptr_t)a.C & 15) == 0,
+                 "linear: pointers must be 16-byte aligned");
+    VZ_CHECK_ARG(a.act >= 0 && a.act <= 3, "linear: unknown activation %d", a.act);
+    if (a.act == VZ_ACT_SWIGLU) {
+        VZ_CHECK_ARG(a.N % 32 == 0 && !a.bias, "linear: SwiGLU needs N %% 32 == 0 and no bias");
+        VZ_CHECK_ARG(a.ldc >= a.N / 2, "linear: ldc too small");
+    } else {
+        VZ_CHECK_ARG(a.ldc >= a.N, "linear: ldc=%d < N=%d", a.ldc, a.N);
+    }
+    VZ_CHECK_ARG(!a.residual || ((uintptr_t)a.residual & 7) == 0, "linear: residual must be 8-byte aligned");
+    return VZ_OK;
+}
+
+}  // namespace
+
+int vz_launch_gemm(const LinearArgs& a, hipStream_t s) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    VZ_CHECK_ARG(!a.norm_w, "linear: fused RMSNorm prologue exists on the GEMV path only");
+    GemmParams p;
+    p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.residual = a.residual;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr;
+    p.act = a.act; p.out_fp32 = a.out_fp32;
+    p.tiles_m = (a.M + BM - 1) / BM;
+    p.tiles_n = (a.N + BN - 1) / BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), GEMM_LDS, s, p);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
+static bool gemv_ok(const LinearArgs& a) {
+    if (a.M > 8 || (a.K % 512) != 0) return false;
+    int mb = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
+    return (size_t)mb * a.K * 2 + 64 <= 64 * 1024;
+}
+
+int vz_launch_gemv(const LinearArgs& a, hipStream_t s) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    VZ_CHECK_ARG(gemv_ok(a), "gemv: needs M <= 8, K %% 512 == 0 and M*K*2 <= 64 KiB (M=%d K=%d)", a.M, a.K);
+    GemvParams p;
+    p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.residual = a.residual; p.norm_w = a.norm_w;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr;
+    p.act = a.act; p.out_fp32 = a.out_fp32; p.norm_eps = a.norm_eps;
+    p.units = a.act == VZ_ACT_SWIGLU ? a.N / 2 : (a.N + 1) / 2;
+    int blocks = (p.units + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    const int mb = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
+    const size_t lds = (size_t)mb * a.K * 2 + 64;
+#define VZ_GEMV_CASE(MB)                                                                                          \
+    case MB: {                                                                                                    \
+        static size_t max_lds_##MB = 0;                                                                           \
+        if (lds > max_lds_##MB) {                                                                                 \
+            VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<MB>,                                   \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));             \
+            max_lds_##MB = 64 * 1024;                                                                             \
+        }                                                                                                         \
+        hipLaunchKernelGGL(gemv_bf16_kernel<MB>, dim3(blocks), dim3(256), lds, s, p);                             \
+    } break;
+    switch (mb) {
+        VZ_GEMV_CASE(1)
+        VZ_GEMV_CASE(2)
+        VZ_GEMV_CASE(4)
+        VZ_GEMV_CASE(8)
+    }
+#undef VZ_GEMV_CASE
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
+int vz_launch_linear(const LinearArgs& a, hipStream_t s) {
+    if (gemv_ok(a)) return vz_launch_gemv(a, s);
+    return vz_launch_gemm(a, s);
+}

@@ -1,0 +1,131 @@
+// Shared device helpers and launch plumbing for libviszephyr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/viszephyr.h"
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+
+#define VZ_WAVE 64
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+// round-to-nearest-even; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---- host-side error plumbing ----
+void vz_set_error(const char* fmt, ...);
+#define VZ_CHECK_ARG(cond, ...)                  \
+    do {                                         \
+        if (!(cond)) {                           \
+            vz_set_error(__VA_ARGS__);           \
+            return VZ_ERR_ARG;                   \
+        }                                        \
+    } while (0)
+#define VZ_CHECK_HIP(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            vz_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return VZ_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+#define VZ_LAUNCH_CHECK()                                                                    \
+    do {                                                                                     \
+        hipError_t _e = hipGetLastError();                                                   \
+        if (_e != hipSuccess) {                                                              \
+            vz_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return VZ_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+// ---- internal launchers shared between the op-level C ABI and the engine ----
+struct LinearArgs {
+    const bf16_t* A; int lda;
+    const bf16_t* W; int ldw;
+    void* C; int ldc;
+    int M, N, K;
+    const float* bias;
+    const bf16_t* residual; int ldr;
+    int act; int out_fp32;
+    // optional fused RMSNorm prologue (GEMV path only): x <- bf16(norm_w * x * rsqrt(mean(x^2)+eps))
+    const float* norm_w; float norm_eps;
+};
+int vz_launch_gemm(const LinearArgs& a, hipStream_t s);
+int vz_launch_gemv(const LinearArgs& a, hipStream_t s);
+int vz_launch_linear(const LinearArgs& a, hipStream_t s);  // picks by M
+
+int vz_launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const float* w, const float* b, int rows,
+                        int cols, float eps, hipStream_t s);
+int vz_launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const float* w, int rows, int cols, float eps,
+                      hipStream_t s);
+
+struct AttnArgs {
+    const bf16_t *q, *k, *v;
+    bf16_t* o;
+    int B, Sq, Sk, Hq, Hkv, head_dim;
+    long q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ss, o_hs;
+    float scale;
+    int causal, q_pos0, window;
+    const int* kv_len;
+};
+int vz_launch_attention(const AttnArgs& a, hipStream_t s);
+
+// decode attention: one query token per slot against the KV cache; lengths live on the device
+struct AttnDecodeArgs {
+    const bf16_t* q;      // [B, Hq, D]
+    const bf16_t* kc;     // cache base for this layer: [B][Hkv][max_ctx][D]
+    const bf16_t* vc;
+    bf16_t* o;            // [B, Hq, D]
+    float* part;          // workspace [B*Hq*nsplit*(D+2)]
+    int B, Hq, Hkv, D, max_ctx, nsplit, window;
+    float scale;
+    const int* ctx_len;   // device int32 [B]: keys visible to this step (incl. the token just appended)
+};
+int vz_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
+
+int vz_launch_rope_kv(const bf16_t* qkv, int ld, bf16_t* q_out, bf16_t* kc, bf16_t* vc, const float* cosT,
+                      const float* sinT, const int* pos, const int* slot, int B, int S, int Hq, int Hkv, int D,
+                      int max_ctx, hipStream_t s);
+int vz_launch_gather_rows(const int* kind, const int* idx, int rows, int cols, const bf16_t* table,
+                          const bf16_t* visual, bf16_t* out, hipStream_t s);
+int vz_launch_embed_tokens(const int* ids, int rows, int cols, const bf16_t* table, bf16_t* out, hipStream_t s);
+int vz_launch_im2col(const bf16_t* img, int T, int image, int patch, int kpad, bf16_t* out, hipStream_t s);
+int vz_launch_clip_assemble(const bf16_t* patch_out, const bf16_t* cls, const bf16_t* pos, int T, int tokens, int C,
+                            bf16_t* out, hipStream_t s);
+int vz_launch_fusion(const bf16_t* hs_base, long layer_stride, int first_layer, int groups, int per_group, int T,
+                     int tokens, int C, bf16_t* out, hipStream_t s);
+int vz_launch_argmax(const float* logits, int rows, int cols, int* ids, int* pos, int* ctx, int* out_ids,
+                     int out_stride, const int* step, hipStream_t s);
+int vz_launch_copy_rows(const bf16_t* src, long src_stride, bf16_t* dst, long dst_stride, int rows, int cols,
+                        hipStream_t s);
+int vz_launch_step_advance(int* step, hipStream_t s);
