@@ -88,6 +88,20 @@ int vz_op_attention(const void* d_q, const void* d_k, const void* d_v, void* d_o
                     float scale, int causal, int q_pos0, int window, const int* d_kv_len,
                     vz_stream stream);
 
+/* RoPE (rotate-half, hf:models/mistral/modeling_mistral.py:51-81) on the Q and K heads of a fused QKV row
+ * [B*S, (Hq+2Hkv)*D] + append of K/V to the cache [B][Hkv][max_ctx][D].  d_pos / d_slot: int32 [B*S] position
+ * id and cache slot of every token (slot < 0: token not cached).  d_q_out bf16 [B*S,Hq,D].  D = 128. */
+int vz_op_rope_kv(const void* d_qkv, int ld, void* d_q_out, void* d_kcache, void* d_vcache, const float* d_cos,
+                  const float* d_sin, const int* d_pos, const int* d_slot, int B, int S, int Hq, int Hkv, int head_dim,
+                  int max_ctx, vz_stream stream);
+
+/* one query token per slot against the KV cache (decode step of hf:...modeling_mistral.py:139-178).
+ * d_q / d_o bf16 [B,Hq,D]; caches [B][Hkv][max_ctx][D]; d_ctx_len int32 [B] = keys visible (device memory, so a
+ * captured graph replays for every step); d_workspace fp32 [B*Hq*nsplit*(D+2)]. */
+int vz_op_attention_decode(const void* d_q, const void* d_kcache, const void* d_vcache, void* d_o, float* d_workspace,
+                           int B, int Hq, int Hkv, int head_dim, int max_ctx, int nsplit, int window, float scale,
+                           const int* d_ctx_len, vz_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * 2. Engine
  * ------------------------------------------------------------------------------------------ */

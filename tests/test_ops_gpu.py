@@ -1,0 +1,296 @@
+"""Operator-level parity of the HIP kernels (through the C ABI) against fp32 references computed
+from the same bf16-rounded inputs.  Tolerances: outputs are bf16, so one rounding step is
+2^-9 = 1.95e-3 relative; fp32-output kernels are held to 1e-4."""
+import math
+
+import pytest
+import torch
+
+from util import bf16r, check_close
+
+pytestmark = pytest.mark.gpu
+
+BF16_MAX = 6e-3   # max-norm: <= 1.5 bf16 ulp of the largest element
+BF16_L2 = 3e-3    # relative L2: one bf16 rounding is ~1.1e-3 rms
+
+
+@pytest.fixture(scope="module")
+def B():
+    from vz_hip import binding
+    binding.load_library()
+    return binding
+
+
+def _rand(shape, std=1.0, seed=0, device="cuda"):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * std).to(device)
+
+
+def _ref_linear(x, w, bias, residual, act):
+    y = bf16r(x).double() @ bf16r(w).double().t()
+    if bias is not None:
+        y = y + bias.double()
+    if act == 1:
+        y = y * torch.sigmoid(1.702 * y)
+    elif act == 2:
+        y = torch.nn.functional.gelu(y)
+    elif act == 3:
+        N = w.shape[0]
+        yy = y.view(y.shape[0], N // 32, 2, 16)
+        y = (torch.nn.functional.silu(yy[:, :, 0]) * yy[:, :, 1]).reshape(y.shape[0], N // 2)
+    if residual is not None:
+        y = y + bf16r(residual).double()
+    return y.float()
+
+
+# (M, N, K): CLIP (577*T rows), patch embed K=640, Zephyr shapes, ragged N = 32001, tiny M through the tile kernel
+GEMM_SHAPES = [(577 * 2, 3072, 1024), (576, 1024, 640), (127, 6144, 4096), (300, 4096, 14336 // 4), (64, 32001, 512),
+               (1, 256, 128), (129, 130, 64), (2048, 4096, 4096)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_plain(B, M, N, K):
+    x = _rand((M, K), 1.0, 1).bfloat16()
+    w = _rand((N, K), 0.05, 2).bfloat16()
+    out = B.linear(x, w, impl=0)
+    check_close(f"gemm {M}x{N}x{K}", out, _ref_linear(x, w, None, None, 0), BF16_MAX, BF16_L2)
+
+
+def test_gemm_fp32_out_matches_tightly(B):
+    M, N, K = 200, 32001, 4096
+    x = _rand((M, K), 1.0, 3).bfloat16()
+    w = _rand((N, K), 0.02, 4).bfloat16()
+    out = B.linear(x, w, out_fp32=True, impl=0)
+    assert out.dtype == torch.float32 and out.shape == (M, N)
+    check_close("gemm fp32 out", out, _ref_linear(x, w, None, None, 0), 1e-4, 1e-4)
+
+
+def test_gemm_identity_asymmetric(B):
+    """A = I against an asymmetric W: catches a transposed C write or a wrong fragment map exactly."""
+    K = 128
+    x = torch.eye(K, device="cuda").bfloat16()
+    w = (torch.arange(192 * K, device="cuda").view(192, K) % 251 - 125).float().bfloat16()
+    out = B.linear(x, w, out_fp32=True, impl=0)
+    assert torch.equal(out, w.float().t().contiguous())
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_gemm_bias_act_residual(B, act):
+    M, N, K = 577, 4096, 1024
+    x = _rand((M, K), 1.0, 5).bfloat16()
+    w = _rand((N, K), 0.05, 6).bfloat16()
+    bias = _rand((N,), 0.5, 7)
+    res = _rand((M, N), 1.0, 8).bfloat16()
+    out = B.linear(x, w, bias=bias, residual=res, act=act, impl=0)
+    check_close(f"gemm epilogue act{act}", out, _ref_linear(x, w, bias, res, act), BF16_MAX, BF16_L2)
+
+
+def test_gemm_residual_in_place(B):
+    """the engine adds the residual into the very buffer it writes (C aliases residual)."""
+    M, N, K = 300, 1024, 4096
+    x = _rand((M, K), 1.0, 9).bfloat16()
+    w = _rand((N, K), 0.02, 10).bfloat16()
+    res = _rand((M, N), 1.0, 11).bfloat16()
+    ref = _ref_linear(x, w, None, res, 0)
+    buf = res.clone()
+    import ctypes as C
+    B.check(B.lib().vz_op_linear_impl(0, B.ptr(x), K, B.ptr(w), K, B.ptr(buf), N, M, N, K, None, B.ptr(buf), N, 0, 0,
+                                      B.stream_ptr()))
+    check_close("gemm in-place residual", buf, ref, BF16_MAX, BF16_L2)
+
+
+@pytest.mark.parametrize("M", [130, 1])
+def test_gemm_swiglu(B, M):
+    N, K = 2 * 1792, 4096
+    x = _rand((M, K), 1.0, 12).bfloat16()
+    w = _rand((N, K), 0.03, 13).bfloat16()
+    for impl in (0, 1):
+        if impl == 1 and M > 8:
+            continue
+        out = B.linear(x, w, act=3, impl=impl)
+        assert out.shape == (M, N // 2)
+        check_close(f"swiglu impl{impl} M{M}", out, _ref_linear(x, w, None, None, 3), BF16_MAX, BF16_L2)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 6144, 4096), (1, 4096, 14336), (2, 4096, 4096), (4, 1024, 4096), (1, 32001, 4096),
+                                   (3, 257, 1024)])
+def test_gemv(B, M, N, K):
+    x = _rand((M, K), 1.0, 14).bfloat16()
+    w = _rand((N, K), 0.03, 15).bfloat16()
+    res = _rand((M, N), 1.0, 16).bfloat16()
+    bias = _rand((N,), 0.3, 17)
+    out = B.linear(x, w, bias=bias, residual=res, impl=1)
+    check_close(f"gemv {M}x{N}x{K}", out, _ref_linear(x, w, bias, res, 0), BF16_MAX, BF16_L2)
+    out32 = B.linear(x, w, out_fp32=True, impl=1)
+    check_close(f"gemv fp32 {M}x{N}x{K}", out32, _ref_linear(x, w, None, None, 0), 1e-4, 1e-4)
+
+
+def test_linear_dispatch_rejects_bad_shapes(B):
+    x = torch.zeros(4, 100, device="cuda").bfloat16()
+    w = torch.zeros(8, 100, device="cuda").bfloat16()
+    with pytest.raises(ValueError):
+        B.linear(x, w)                      # K not a multiple of 64
+    with pytest.raises(ValueError):
+        B.linear(torch.zeros(4, 128).bfloat16(), torch.zeros(8, 128).bfloat16())   # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("rows,cols", [(577 * 3, 1024), (96, 4096), (576 * 2, 5120), (5, 512)])
+def test_layernorm(B, rows, cols):
+    x = (_rand((rows, cols), 2.0, 18) + 0.7).bfloat16()
+    w = _rand((cols,), 0.2, 19) + 1.0
+    b = _rand((cols,), 0.2, 20)
+    out = B.layernorm(x, w, b, 1e-5)
+    ref = torch.nn.functional.layer_norm(bf16r(x).double(), (cols,), w.double(), b.double(), 1e-5).float()
+    check_close(f"layernorm {rows}x{cols}", out, ref, BF16_MAX, BF16_L2)
+
+
+def test_layernorm_zero_rows_give_bias(B):
+    """Q-Former block 0 sees zero-padded text rows: LN(0) must be exactly the bias."""
+    cols = 4096
+    x = torch.zeros(7, cols, device="cuda").bfloat16()
+    w = _rand((cols,), 0.2, 21) + 1.0
+    b = _rand((cols,), 0.2, 22)
+    out = B.layernorm(x, w, b, 1e-5)
+    assert torch.equal(out.float(), bf16r(b).unsqueeze(0).expand(7, -1))
+
+
+@pytest.mark.parametrize("rows,cols", [(127, 4096), (1, 4096), (2048, 4096)])
+def test_rmsnorm(B, rows, cols):
+    x = _rand((rows, cols), 3.0, 23).bfloat16()
+    w = _rand((cols,), 0.2, 24) + 1.0
+    out = B.rmsnorm(x, w, 1e-5)
+    xf = bf16r(x).double()
+    ref = (w.double() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))).float()
+    check_close(f"rmsnorm {rows}x{cols}", out, ref, BF16_MAX, BF16_L2)
+
+
+def _ref_attention(q, k, v, scale, causal, q_pos0, window, kv_len):
+    Bn, Sq, Hq, D = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    qf, kf, vf = (bf16r(t).double() for t in (q, k, v))
+    kf = kf.repeat_interleave(Hq // Hkv, dim=2)
+    vf = vf.repeat_interleave(Hq // Hkv, dim=2)
+    s = torch.einsum("bqhd,bkhd->bhqk", qf, kf) * scale
+    kp = torch.arange(Sk, device=q.device).view(1, 1, 1, Sk)
+    keep = torch.ones(Bn, 1, Sq, Sk, dtype=torch.bool, device=q.device)
+    if kv_len is not None:
+        keep = keep & (kp < kv_len.view(Bn, 1, 1, 1))
+    if causal:
+        qp = (torch.arange(Sq, device=q.device) + q_pos0).view(1, 1, Sq, 1)
+        keep = keep & (kp <= qp)
+        if window > 0:
+            keep = keep & (kp > qp - window)
+    s = s.masked_fill(~keep, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return torch.einsum("bhqk,bkhd->bqhd", p, vf).float()
+
+
+ATTN_CASES = [
+    # name, B, Sq, Sk, Hq, Hkv, D, causal, q_pos0, window, ragged kv_len
+    ("clip", 2, 577, 577, 16, 16, 64, False, 0, 0, False),
+    ("zephyr prefill", 1, 300, 300, 32, 8, 128, True, 0, 4096, False),
+    ("zephyr padded batch", 2, 200, 200, 8, 2, 128, True, 0, 4096, True),
+    ("zephyr window", 1, 260, 260, 4, 1, 128, True, 0, 100, False),
+    ("qformer self blk0", 2, 32, 63, 8, 8, 512, False, 0, 0, False),
+    ("qformer cross", 3, 32, 576, 8, 8, 512, False, 0, 0, False),
+    ("qformer self", 2, 32, 32, 8, 8, 512, False, 0, 0, False),
+    ("single key", 1, 5, 1, 4, 4, 64, False, 0, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_attention(B, case):
+    name, Bn, Sq, Sk, Hq, Hkv, D, causal, q_pos0, window, ragged = case
+    q = _rand((Bn, Sq, Hq, D), 1.0, 30).bfloat16()
+    k = _rand((Bn, Sk, Hkv, D), 1.0, 31).bfloat16()
+    v = _rand((Bn, Sk, Hkv, D), 1.0, 32).bfloat16()
+    kv_len = None
+    if ragged:
+        kv_len = torch.tensor([Sk, Sk // 2 + 3][:Bn], dtype=torch.int32, device="cuda")
+    scale = D ** -0.5
+    out = B.attention(q, k, v, scale, causal, q_pos0, window, kv_len)
+    ref = _ref_attention(q, k, v, scale, causal, q_pos0, window, kv_len)
+    if ragged:   # padded query rows (beyond a row's own length) are don't-care
+        for b in range(Bn):
+            out[b, int(kv_len[b]):] = 0
+            ref[b, int(kv_len[b]):] = 0
+    check_close(f"attention {name}", out, ref, 8e-3, 4e-3)
+
+
+def test_attention_strided_fused_qkv(B):
+    """the engine hands Q/K/V as column slices of one fused projection output (CLIP layout)."""
+    T, S, H, D = 2, 577, 16, 64
+    qkv = _rand((T, S, 3 * H * D), 1.0, 33).bfloat16()
+    q = qkv[:, :, :H * D].view(T, S, H, D)
+    k = qkv[:, :, H * D:2 * H * D].view(T, S, H, D)
+    v = qkv[:, :, 2 * H * D:].view(T, S, H, D)
+    out = B.attention(q, k, v, 0.125)
+    check_close("attention strided", out, _ref_attention(q, k, v, 0.125, False, 0, 0, None), 8e-3, 4e-3)
+
+
+def test_attention_softmax_spike(B):
+    """one key dominating late in the sequence forces the online-softmax rescale branch."""
+    Bn, S, H, D = 1, 256, 2, 128
+    q = _rand((Bn, S, H, D), 1.0, 34).bfloat16()
+    k = _rand((Bn, S, H, D), 1.0, 35).bfloat16()
+    v = _rand((Bn, S, H, D), 1.0, 36).bfloat16()
+    k[0, 200] = (q[0, 17] * 4).bfloat16()
+    out = B.attention(q, k, v, D ** -0.5)
+    check_close("attention spike", out, _ref_attention(q, k, v, D ** -0.5, False, 0, 0, None), 8e-3, 4e-3)
+
+
+def test_argmax_first_max(B):
+    x = _rand((3, 32001), 1.0, 37)
+    x[1, 777] = 50.0
+    x[1, 31000] = 50.0          # tie: torch.argmax returns the first
+    x[2, 32000] = 99.0
+    ids = B.argmax(x)
+    assert ids.tolist() == torch.argmax(x, dim=-1).tolist()
+    assert ids[1].item() == 777 and ids[2].item() == 32000
+
+
+def test_rope_kv_append(B):
+    """rotate-half RoPE on Q/K + cache append against the formula of hf:models/mistral/modeling_mistral.py:51-81."""
+    Bn, S, Hq, Hkv, D, max_ctx = 2, 37, 32, 8, 128, 64
+    qkv = _rand((Bn * S, (Hq + 2 * Hkv) * D), 1.0, 40).bfloat16()
+    pos = (torch.arange(S, dtype=torch.int32).repeat(Bn) + 3).cuda()
+    slot = torch.arange(S, dtype=torch.int32).repeat(Bn)
+    slot[S + 30:] = -1                               # padded tail of the second row is not cached
+    slot = slot.cuda()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))
+    fr = torch.arange(64, dtype=torch.float32).unsqueeze(-1) * inv
+    cos, sin = fr.cos().cuda().contiguous(), fr.sin().cuda().contiguous()
+    kc = torch.zeros(Bn, Hkv, max_ctx, D, device="cuda").bfloat16()
+    vc = torch.zeros_like(kc)
+    q = B.rope_kv(qkv, cos, sin, pos, slot, kc, vc, Bn, S, Hq, Hkv, D)
+    x = bf16r(qkv).view(Bn * S, Hq + 2 * Hkv, D)
+    c = torch.cat([cos, cos], -1)[pos.long()].unsqueeze(1)
+    s_ = torch.cat([sin, sin], -1)[pos.long()].unsqueeze(1)
+    rot = torch.cat([-x[..., D // 2:], x[..., :D // 2]], -1)
+    ref = x * c + rot * s_
+    check_close("rope q", q, ref[:, :Hq], BF16_MAX, BF16_L2)
+    kref = torch.zeros(Bn, Hkv, max_ctx, D, device="cuda")
+    vref = torch.zeros_like(kref)
+    for b in range(Bn):
+        n = S if b == 0 else 30
+        kref[b, :, :n] = ref[b * S:b * S + n, Hq:Hq + Hkv].permute(1, 0, 2)
+        vref[b, :, :n] = x[b * S:b * S + n, Hq + Hkv:].permute(1, 0, 2)
+    check_close("rope k cache", kc, kref, BF16_MAX, BF16_L2)
+    assert torch.equal(vc.float(), vref)
+
+
+@pytest.mark.parametrize("ctx,nsplit,window", [(1, 4, 0), (77, 8, 0), (1500, 16, 0), (700, 8, 256), (2047, 16, 4096)])
+def test_attention_decode(B, ctx, nsplit, window):
+    Bn, Hq, Hkv, D, max_ctx = 2, 32, 8, 128, 2048
+    q = _rand((Bn, Hq, D), 1.0, 41).bfloat16()
+    kc = _rand((Bn, Hkv, max_ctx, D), 1.0, 42).bfloat16()
+    vc = _rand((Bn, Hkv, max_ctx, D), 1.0, 43).bfloat16()
+    lens = torch.tensor([ctx, max(1, ctx // 2)], dtype=torch.int32, device="cuda")
+    out = B.attention_decode(q, kc, vc, lens, D ** -0.5, nsplit, window)
+    for b in range(Bn):
+        n = int(lens[b])
+        lo = max(0, n - window) if window > 0 else 0
+        ref = _ref_attention(q[b:b + 1].unsqueeze(1), kc[b:b + 1, :, lo:n].permute(0, 2, 1, 3), vc[b:b + 1, :, lo:n].permute(0, 2, 1, 3),
+                             D ** -0.5, False, 0, 0, None)
+        check_close(f"attention decode ctx{n} b{b}", out[b], ref[0, 0], BF16_MAX, BF16_L2)

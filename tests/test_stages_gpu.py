@@ -1,0 +1,291 @@
+"""Stage- and API-level parity of the MI355X path against the CPU oracle and the golden vectors.
+
+Model under test: the full-width architecture (CLIP-L/14-336, 8-block Q-Former, Zephyr width 4096 /
+14336, vocab 32000) with 2 decoder layers and the hash-generated weights of seed 0 - the exact model
+the golden vectors in tests/golden/pin_l2.npz were produced on by the imported reference.
+
+Tolerances.  Single kernels are held to one bf16 rounding (tests/test_ops_gpu.py; fp32-output kernels
+to 1e-4).  Through a stack of layers two *correct* bf16 implementations decorrelate: every bf16 store
+is an independent 2^-9 rounding, so the HIP path and the bf16-rounding oracle differ from each other by
+about as much as either differs from the fp32 reference.  The stage tests therefore measure the bf16
+BAND itself and hold the HIP path to it:
+    e_or  = ||oracle_bf16 - oracle_fp32|| / ||oracle_fp32||     (what ideal bf16 arithmetic costs)
+    e_hip = ||hip - oracle_fp32||        / ||oracle_fp32||      must be <= 1.6 * e_or + 5e-4
+    e_x   = ||hip - oracle_bf16||        / ||oracle_bf16||      must be <= 2.2 * e_or + 5e-4
+i.e. the GPU path may not be measurably worse than bf16 arithmetic done in fp32 on the CPU, and the
+fp32 golden vectors of the reference itself bound it in absolute terms (per-test constants).
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import check_close, errs, load_golden, record, sub
+
+pytestmark = pytest.mark.gpu
+
+PINPOINTS = "[[336, 672], [672, 336], [336, 1008], [1008, 336]]"
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import vz_oracle as O
+    from vz_hip import synth
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    cfg = synth.ArchConfig(n_layers=2)
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.n_layers,
+                         num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab,
+                         rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, sliding_window=cfg.sliding_window,
+                         eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    hf.image_aspect_ratio = "anyres"
+    hf.mm_grid_pinpoints = PINPOINTS
+    hf.mm_hidden_size = 5120
+    hf.mm_vision_select_layer = "-2,-5,-8,-11,6"
+    hf.mm_vision_select_feature = "patch"
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=2, max_ctx=512, max_tiles=4, max_text=64)
+    # the oracle's fp32 weights: generated on the device (bit-identical to the CPU generator), copied to the host
+    sd = {k: v.cpu() for k, v in synth.iter_state_dict(cfg, 0, device=model.device)}
+    torch.cuda.synchronize()
+    return dict(cfg=cfg, model=model, sd=sd, O=O, synth=synth, gold=load_golden(2))
+
+
+def band(name, hip, o_bf16, o_fp32):
+    """hold the HIP result to the measured bf16 band (module docstring)."""
+    e_or = errs(o_bf16, o_fp32)[1]
+    mx_hip, e_hip = errs(hip, o_fp32)
+    mx_x, e_x = errs(hip, o_bf16)
+    record(name, e_oracle_bf16_vs_fp32=e_or, e_hip_vs_fp32=e_hip, e_hip_vs_bf16=e_x, max_hip_vs_fp32=mx_hip)
+    assert torch.isfinite(hip.float()).all(), f"{name}: non-finite"
+    assert e_hip <= 1.6 * e_or + 5e-4, f"{name}: hip vs fp32 {e_hip:.3e} outside the bf16 band (oracle-bf16 vs fp32 {e_or:.3e})"
+    assert e_x <= 2.2 * e_or + 5e-4, f"{name}: hip vs oracle-bf16 {e_x:.3e} (band {e_or:.3e})"
+
+
+def _gold_check(env, name, got, max_tol, l2_tol):
+    g = env["gold"]
+    ref = torch.from_numpy(g[name + ".sub"])
+    mine = sub(got.float().cpu(), int(g[name + ".stride"]))
+    assert tuple(got.shape) == tuple(g[name + ".shape"].tolist())
+    return check_close("golden " + name, mine, ref, max_tol, l2_tol)
+
+
+def test_weights_match_generator(env):
+    """the device-side generator + packer reproduce the CPU generator bit for bit (spot checks)."""
+    eng, sd, cfg = env["model"].engine, env["sd"], env["cfg"]
+    q = sd["model.layers.1.self_attn.q_proj.weight"].bfloat16()
+    assert torch.equal(eng.w["llm.1.qkv.w"][:4096].cpu(), q)
+    g = sd["model.layers.0.mlp.gate_proj.weight"].bfloat16()
+    u = sd["model.layers.0.mlp.up_proj.weight"].bfloat16()
+    gu = eng.w["llm.0.gu.w"].cpu().view(-1, 2, 16, 4096)
+    assert torch.equal(gu[:, 0].reshape(-1, 4096), g) and torch.equal(gu[:, 1].reshape(-1, 4096), u)
+    cpu = env["synth"].hash_normal("lm_head.weight", (cfg.vocab, cfg.hidden), 0.02, 0)[:64]
+    assert torch.equal(cpu, sd["lm_head.weight"][:64])
+
+
+def test_clip_tower_and_fusion(env):
+    O, cfg, sd, eng = env["O"], env["cfg"], env["sd"], env["model"].engine
+    tiles = env["synth"].synth_tiles(3, seed=1)
+    fused, hid = eng.clip_fused_features(tiles, return_hidden=True)
+    hs = O.clip_hidden_states(cfg, sd, tiles, O.BF16)
+    hs32 = O.clip_hidden_states(cfg, sd, tiles, O.FP32)
+    check_close("clip hs0 vs oracle-bf16", hid[0], hs[0], 8e-3, 1e-3)      # patch GEMM + assemble + LN only
+    for i in (1, 12, 24):
+        band(f"clip hs{i}", hid[i], hs[i], hs32[i])
+    band("fused", fused, O.fusion(cfg, hs, O.BF16), O.fusion(cfg, hs32, O.FP32))
+    # against the reference's fp32 outputs: 24 layers of bf16 activations
+    _gold_check(env, "A.clip.hs24", hid[24], 5e-2, 1.5e-2)
+    _gold_check(env, "A.fused", fused, 5e-2, 1.5e-2)
+    env["fused"] = fused
+    env["tiles"] = tiles
+
+
+def test_fusion_rejects_wrong_image_size(env):
+    with pytest.raises(ValueError):
+        env["model"].engine.clip_fused_features(torch.zeros(1, 3, 224, 224))
+
+
+def test_qformer(env):
+    O, cfg, sd, model = env["O"], env["cfg"], env["sd"], env["model"]
+    eng = model.engine
+    tiles = env["synth"].synth_tiles(3, seed=1)
+    ids = env["synth"].synth_ids(32, cfg.vocab, image_pos=5, seed=2)
+    text_ids = ids[ids != -200]
+    te = O.embed_tokens(sd, text_ids, O.BF16)
+    feats = O.clip_tower(cfg, sd, tiles, O.BF16)                        # same features into both sides
+    ref, blocks = O.qformer(cfg, sd, feats, te.unsqueeze(0).expand(3, -1, -1), O.BF16, return_blocks=True)
+    ref32 = O.qformer(cfg, sd, feats, te.unsqueeze(0).expand(3, -1, -1), O.FP32)
+    # shared form (one sample, three tiles) and the per-tile form must agree with the oracle and with each other
+    shared = eng.qformer(feats.bfloat16(), te.bfloat16().unsqueeze(0), [0, 0, 0])
+    per_tile = eng.qformer(feats.bfloat16(), te.bfloat16().unsqueeze(0).expand(3, -1, -1).contiguous(), [0, 1, 2])
+    band("qformer shared", shared, ref, ref32)
+    band("qformer per-tile", per_tile, ref, ref32)
+    assert torch.equal(shared, per_tile), "sharing block 0's self-attention across a sample's tiles changed the result"
+    no_text = eng.qformer(feats.bfloat16(), None, [0, 0, 0])
+    band("qformer no text", no_text, O.qformer(cfg, sd, feats, None, O.BF16), O.qformer(cfg, sd, feats, None, O.FP32))
+
+
+def test_splice_api_matches_oracle_batch(env):
+    """case B of the golden set: batch of 2, unequal lengths, padding mask, labels, position ids."""
+    O, cfg, sd, model, g = env["O"], env["cfg"], env["sd"], env["model"], env["gold"]
+    S = env["synth"]
+    tb0, tb1 = S.synth_tiles(2, seed=3), S.synth_tiles(1, seed=4)
+    ids = torch.full((2, 20), 2, dtype=torch.long)
+    ids[0] = S.synth_ids(20, cfg.vocab, image_pos=1, seed=5)
+    ids[1, :13] = S.synth_ids(13, cfg.vocab, image_pos=7, seed=6)
+    mask = torch.zeros(2, 20, dtype=torch.long)
+    mask[0] = 1
+    mask[1, :13] = 1
+    pos = torch.arange(20).unsqueeze(0).expand(2, -1).contiguous()
+    lab = ids.clone()
+    lab[ids == -200] = -100
+    r = model.prepare_inputs_labels_for_multimodal(ids, pos, mask, None, lab, [tb0, tb1], None)
+    assert r[0] is None and r[3] is None
+    assert np.array_equal(r[1].cpu().numpy(), g["B.position_ids"])
+    assert np.array_equal(r[2].cpu().numpy(), g["B.attention_mask"]) and r[2].dtype == mask.dtype
+    assert np.array_equal(r[5].cpu().numpy(), g["B.labels"])
+    # embeddings: visual rows through the HIP encoder, text rows exact bf16 table rows
+    o = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids, pos, mask, None, lab, [tb0, tb1], P=O.BF16)
+    o32 = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids, pos, mask, None, lab, [tb0, tb1], P=O.FP32)
+    band("splice embeds", r[4], o[4], o32[4])
+    _gold_check(env, "B.splice.embeds", r[4], 5e-2, 1.5e-2)
+    text_rows = torch.from_numpy(g["B.labels"]) != -100
+    text_rows[:, 0] = True
+    # rows holding text embeddings are bit-exact copies of the bf16 table
+    tbl = sd["model.embed_tokens.weight"].bfloat16()
+    assert torch.equal(r[4][0, 0].cpu(), tbl[ids[0, 0]])
+    # early-outs of the reference (:148-149)
+    assert model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, None)[4] is None
+    assert model.prepare_inputs_labels_for_multimodal(ids[:, :1], None, None, None, None, [tb0, tb1])[4] is None
+    env["B"] = dict(ids=ids, mask=mask, pos=pos, lab=lab, tiles=[tb0, tb1], embeds=r[4], omask=r[2], opos=r[1])
+
+
+def test_forward_logits_case_a(env):
+    """C1 shape: 3 tiles + 32 ids -> logits [1,127,32000] for all positions."""
+    O, cfg, sd, model = env["O"], env["cfg"], env["sd"], env["model"]
+    S = env["synth"]
+    tiles = S.synth_tiles(3, seed=1)
+    ids = S.synth_ids(32, cfg.vocab, image_pos=5, seed=2).unsqueeze(0)
+    out = model(input_ids=ids, images=[tiles])
+    assert tuple(out.logits.shape) == (1, 127, cfg.vocab) and out.logits.dtype == torch.float32
+    emb = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids, None, None, None, None, [tiles], P=O.BF16)[4]
+    ref, _ = O.llm_forward(cfg, sd, emb, P=O.BF16)
+    emb32 = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids, None, None, None, None, [tiles], P=O.FP32)[4]
+    ref32, _ = O.llm_forward(cfg, sd, emb32, P=O.FP32)
+    band("logits A", out.logits, ref, ref32)
+    _gold_check(env, "A.logits", out.logits, 5e-2, 2e-2)
+    last = torch.from_numpy(env["gold"]["A.logits.last"])
+    mx, l2 = errs(out.logits[0, -1].cpu(), last)
+    record("logits A last vs reference fp32", max_err=mx, l2_err=l2)
+    assert l2 < 2e-2
+
+
+def test_forward_batch_with_padding_and_loss(env):
+    O, cfg, sd, model = env["O"], env["cfg"], env["sd"], env["model"]
+    b = env.get("B")
+    if b is None:
+        pytest.skip("depends on test_splice_api_matches_oracle_batch")
+    out = model(input_ids=b["ids"], attention_mask=b["mask"], position_ids=b["pos"], labels=b["lab"], images=b["tiles"])
+    emb = O.prepare_inputs_labels_for_multimodal(cfg, sd, b["ids"], b["pos"], b["mask"], None, b["lab"], b["tiles"], P=O.BF16)
+    ref, _ = O.llm_forward(cfg, sd, emb[4], attention_mask=emb[2], position_ids=emb[1], P=O.BF16)
+    valid = emb[2].bool()
+    e32 = O.prepare_inputs_labels_for_multimodal(cfg, sd, b["ids"], b["pos"], b["mask"], None, b["lab"], b["tiles"], P=O.FP32)
+    r32, _ = O.llm_forward(cfg, sd, e32[4], attention_mask=e32[2], position_ids=e32[1], P=O.FP32)
+    band("logits B (valid rows)", out.logits.cpu()[valid], ref[valid], r32[valid])
+    _gold_check(env, "B.logits.valid", out.logits.cpu()[valid], 5e-2, 2e-2)
+    assert abs(float(out.loss) - float(env["gold"]["B.loss"])) < 0.05 * abs(float(env["gold"]["B.loss"]))
+
+
+def test_generate_greedy_matches_oracle_and_reference(env):
+    O, cfg, sd, model, g = env["O"], env["cfg"], env["sd"], env["model"], env["gold"]
+    S = env["synth"]
+    tiles = S.synth_tiles(3, seed=1)
+    ids = S.synth_ids(32, cfg.vocab, image_pos=5, seed=2).unsqueeze(0)
+    n_new = 6
+    got = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n_new, eos_token_id=None,
+                         pad_token_id=2, use_cache=True)
+    assert got.dtype == torch.long and tuple(got.shape) == (1, n_new)          # new tokens only
+    emb = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids, None, None, None, None, [tiles], P=O.BF16)[4]
+    ref_ids, ref_logits = O.greedy_generate(cfg, sd, emb, n_new, P=O.BF16, return_logits=True)
+    # a greedy step may legitimately differ only where the oracle's own top-2 margin is inside the bf16 band
+    top2 = ref_logits[0].topk(2, dim=-1).values
+    margin = (top2[:, 0] - top2[:, 1]) / ref_logits[0].abs().amax(-1)
+    for t in range(n_new):
+        if int(got[0, t]) != int(ref_ids[0, t]):
+            assert float(margin[t]) < 2e-3, f"step {t}: id {int(got[0, t])} vs oracle {int(ref_ids[0, t])}, margin {float(margin[t]):.2e}"
+            break
+    record("generate A", got=got[0].tolist(), oracle_bf16=ref_ids[0].tolist(), reference_fp32=g["A.generate.ids"][0].tolist(),
+           min_margin=float(margin.min()))
+    assert got[0].tolist() == g["A.generate.ids"][0].tolist(), "generated ids differ from the reference's fp32 greedy ids"
+
+
+def test_generate_text_only_and_callbacks(env):
+    cfg, model, g = env["cfg"], env["model"], env["gold"]
+    ids = env["synth"].synth_ids(9, cfg.vocab, image_pos=-1, seed=7).unsqueeze(0)
+    got = model.generate(input_ids=ids, images=None, do_sample=False, max_new_tokens=4, eos_token_id=None, pad_token_id=2)
+    assert got[0].tolist() == g["C.generate.ids"][0].tolist()
+
+    class Streamer:
+        def __init__(self):
+            self.puts, self.ended = [], False
+
+        def put(self, v):
+            self.puts.append(v.reshape(-1).tolist())
+
+        def end(self):
+            self.ended = True
+
+    calls = []
+
+    def stop_after_two(input_ids, scores, **kw):
+        calls.append(tuple(input_ids.shape))
+        return input_ids.shape[1] >= 2
+
+    st = Streamer()
+    got2 = model.generate(input_ids=ids, do_sample=False, max_new_tokens=4, eos_token_id=None, streamer=st,
+                          stopping_criteria=[stop_after_two])
+    assert got2[0].tolist() == g["C.generate.ids"][0].tolist()[:2]
+    assert st.ended and st.puts[0] == [] and [p[0] for p in st.puts[1:]] == got2[0].tolist()
+    assert calls == [(1, 1), (1, 2)]
+    # eos stops generation and is included in the output
+    first = g["C.generate.ids"][0].tolist()
+    got3 = model.generate(input_ids=ids, do_sample=False, max_new_tokens=4, eos_token_id=[first[1]])
+    assert got3[0].tolist() == first[:2]
+    with pytest.raises(NotImplementedError):
+        model.generate(input_ids=ids, inputs_embeds=torch.zeros(1, 2, 4096))
+
+
+def test_decode_matches_prefill_logits(env):
+    """teacher forcing: the logits of decode step t must equal the prefill logits at position S+t when the
+    same tokens are fed (KV cache, RoPE positions and the GEMV path against the tile-GEMM path)."""
+    cfg, model = env["cfg"], env["model"]
+    eng = model.engine
+    ids = env["synth"].synth_ids(40, cfg.vocab, image_pos=-1, seed=9)
+    emb = eng.embed_tokens(ids).unsqueeze(0)
+    full, _ = eng.prefill(emb, [40], all_logits=True, last_logits=False)
+    S0 = 33
+    _, last = eng.prefill(emb[:, :S0].contiguous(), [S0], all_logits=False, last_logits=True)
+    check_close("prefill last-row path", last[0], full[0, S0 - 1], 2e-3, 1e-3)
+    O, sd = env["O"], env["sd"]
+    e_cpu = O.embed_tokens(sd, ids.unsqueeze(0), O.BF16)
+    o16, _ = O.llm_forward(cfg, sd, e_cpu, P=O.BF16)
+    o32, _ = O.llm_forward(cfg, sd, O.embed_tokens(sd, ids.unsqueeze(0), O.FP32), P=O.FP32)
+    band("prefill text-only logits", full, o16, o32)
+    for t in range(3):
+        eng.decode_begin(ids[S0 + t:S0 + t + 1].to(torch.int32), [S0 + t], [S0 + t])
+        _, lg = eng.decode_steps(1, return_logits=True)
+        band(f"decode step {t} logits", lg[0, 0], o16[0, S0 + t], o32[0, S0 + t])
+
+
+def test_decode_graph_equals_eager(env):
+    cfg, model = env["cfg"], env["model"]
+    eng = model.engine
+    ids = env["synth"].synth_ids(24, cfg.vocab, image_pos=-1, seed=11)
+    emb = eng.embed_tokens(ids).unsqueeze(0)
+    _, last = eng.prefill(emb, [24])
+    first = last.argmax(-1).to(torch.int32)
+    eng.decode_begin(first, [24], [24])
+    eager, _ = eng.decode_steps(8, return_logits=True)       # debug logits force the eager path
+    _, last = eng.prefill(emb, [24])
+    eng.decode_begin(first, [24], [24])
+    graph = eng.decode_steps(8)
+    assert eager.tolist() == graph.tolist()

@@ -1,0 +1,52 @@
+"""Shared helpers for the parity tests."""
+import json
+import os
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+METRICS = os.path.join(REPO, "gpurun_out", "parity_metrics.jsonl")
+
+
+def bf16r(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def errs(a: torch.Tensor, b: torch.Tensor):
+    """(max-norm error / max|b|, relative L2 error) of a against the reference b."""
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    d = a - b
+    mx = float(d.abs().max() / b.abs().max().clamp_min(1e-30))
+    l2 = float(d.norm() / b.norm().clamp_min(1e-30))
+    return mx, l2
+
+
+def record(name, **kw):
+    """append a metrics line (kept under gpurun_out/ so a GPU run reports its measured error bands)."""
+    try:
+        os.makedirs(os.path.dirname(METRICS), exist_ok=True)
+        with open(METRICS, "a") as f:
+            f.write(json.dumps(dict(name=name, **kw)) + "\n")
+    except OSError:
+        pass
+
+
+def check_close(name, got, ref, max_tol, l2_tol):
+    mx, l2 = errs(got, ref)
+    record(name, max_err=mx, l2_err=l2, max_tol=max_tol, l2_tol=l2_tol)
+    assert torch.isfinite(got.float()).all(), f"{name}: non-finite values"
+    assert mx <= max_tol and l2 <= l2_tol, f"{name}: max-norm err {mx:.3e} (tol {max_tol}), rel-L2 err {l2:.3e} (tol {l2_tol})"
+    return mx, l2
+
+
+def load_golden(layers=2):
+    z = np.load(os.path.join(GOLDEN, f"pin_l{layers}.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def sub(t: torch.Tensor, stride: int, n=4096):
+    return t.reshape(-1)[::stride][:n]

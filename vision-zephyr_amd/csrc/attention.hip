@@ -191,11 +191,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(FlashParams p) {
 template <int HD, int KT>
 int launch_flash(const FlashParams& p, hipStream_t s) {
     constexpr int LDS = KT * (HD * 2 + 16) + HD * (KT * 2 + 8);
-    static bool attr = false;
-    if (!attr) {
-        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn_kernel<HD, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
+    { int r = vz_init_attention_kernels(); if (r) return r; }
     dim3 grid((p.Sq + 63) / 64, p.Hq, p.B);
     hipLaunchKernelGGL((flash_attn_kernel<HD, KT>), grid, dim3(256), LDS, s, p);
     VZ_LAUNCH_CHECK();
@@ -304,6 +300,24 @@ __global__ __launch_bounds__(128) void attn_decode_combine(const float* __restri
 }
 
 }  // namespace
+
+template <int HD, int KT>
+static int set_flash_attr() {
+    constexpr int LDS = KT * (HD * 2 + 16) + HD * (KT * 2 + 8);
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn_kernel<HD, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    return VZ_OK;
+}
+
+int vz_init_attention_kernels() {
+    static bool done = false;
+    if (done) return VZ_OK;
+    int r;
+    if ((r = set_flash_attr<64, 64>())) return r;
+    if ((r = set_flash_attr<128, 64>())) return r;
+    if ((r = set_flash_attr<512, 32>())) return r;
+    done = true;
+    return VZ_OK;
+}
 
 int vz_launch_attention(const AttnArgs& a, hipStream_t s) {
     VZ_CHECK_ARG(a.q && a.k && a.v && a.o, "attention: null pointer");

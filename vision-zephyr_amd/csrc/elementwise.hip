@@ -214,9 +214,9 @@ __global__ __launch_bounds__(256) void fusion_kernel(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += bf16_to_f32(a[j]);
             }
-            const float inv = 1.0f / (float)per_group;
+            const float cnt = (float)per_group;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f32_to_bf16(acc[j] * inv);
+            for (int j = 0; j < 8; ++j) o[j] = f32_to_bf16(acc[j] / cnt);
         }
         *(u16x8*)(out + ((size_t)t * (tokens - 1) + ptk) * ((size_t)(groups + 1) * C) + (size_t)gidx * C + ch * 8) = o;
     }
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256) void fusion_kernel(const bf16_t* __restrict__ 
 // the output ids and advances the per-slot position / context length kept on the device.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int cols, int* __restrict__ ids,
-                                                      int* __restrict__ pos, int* __restrict__ ctx, int* __restrict__ out_ids,
-                                                      int out_stride, const int* __restrict__ step) {
+                                                      int* __restrict__ pos, int* __restrict__ slot, int* __restrict__ len,
+                                                      int* __restrict__ out_ids, int out_stride, const int* __restrict__ step) {
     __shared__ float sv[16];
     __shared__ int si[16];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -255,7 +255,8 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
         ids[row] = bi;
         if (out_ids) out_ids[(size_t)row * out_stride + (step ? *step : 0)] = bi;
         if (pos) pos[row] += 1;
-        if (ctx) ctx[row] += 1;
+        if (slot) slot[row] += 1;
+        if (len) len[row] += 1;
     }
 }
 
@@ -343,10 +344,10 @@ int vz_launch_fusion(const bf16_t* hs_base, long layer_stride, int first_layer, 
     return VZ_OK;
 }
 
-int vz_launch_argmax(const float* logits, int rows, int cols, int* ids, int* pos, int* ctx, int* out_ids, int out_stride,
-                     const int* step, hipStream_t s) {
+int vz_launch_argmax(const float* logits, int rows, int cols, int* ids, int* pos, int* slot, int* len, int* out_ids,
+                     int out_stride, const int* step, hipStream_t s) {
     VZ_CHECK_ARG(logits && ids && rows > 0 && cols > 0, "argmax: bad argument");
-    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, s, logits, cols, ids, pos, ctx, out_ids, out_stride, step);
+    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, s, logits, cols, ids, pos, slot, len, out_ids, out_stride, step);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }

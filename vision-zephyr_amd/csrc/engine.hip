@@ -1,0 +1,716 @@
+// libviszephyr_hip.so - C ABI (include/viszephyr.h) and the stage engine of the Vision-Zephyr
+// forward/generate path on gfx950.  The engine owns workspace + KV cache and sequences the
+// hand-written kernels of one stage on the caller's HIP stream:
+//
+//   vz_clip_fused_features  a8-a10  ref:vis_zephyr/model/vision_encoder/vision_encoder.py:58-117
+//   vz_qformer              a11     ref:vis_zephyr/model/multimodal_projector/builder.py:34-92
+//   vz_embed_splice         a6/a7   ref:vis_zephyr/model/vis_zephyr_arch.py:236-305,476-530
+//   vz_llm_prefill          a12     hf:models/mistral/modeling_mistral.py:202-241,340-466
+//   vz_llm_decode_*         a13     hf:generation/utils.py greedy branch, one hipGraph replay per token
+//
+// Q-Former block 0 (ref builder.py:80-87) keeps only the first 32 rows of a block that ran on
+// [32 queries ; L text tokens].  Those rows depend on the other rows only through the self-attention
+// keys/values, and both the query rows and the text rows are identical for every tile of a sample,
+// so the engine computes block 0's self-attention once per SAMPLE for the 32 query rows (K/V over
+// all 32+L rows) and runs cross-attention/FFN per tile on 32 rows - identical results, without the
+// rows the reference computes and throws away.
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "vz_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void vz_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* vz_last_error(void) { return g_err; }
+extern "C" int vz_abi_version(void) { return 1; }
+extern "C" const char* vz_target_arch(void) { return "gfx950"; }
+
+// ------------------------------------------------------------------------------------------------
+// operator entry points
+// ------------------------------------------------------------------------------------------------
+static LinearArgs mk_linear(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                            const float* bias, const void* residual, int ldr, int act, int out_fp32) {
+    LinearArgs a;
+    a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.bias = bias; a.residual = (const bf16_t*)residual; a.ldr = ldr;
+    a.act = act; a.out_fp32 = out_fp32; a.norm_w = nullptr; a.norm_eps = 0.f;
+    return a;
+}
+
+extern "C" int vz_op_linear(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                            const float* bias, const void* residual, int ldr, int act, int out_fp32, vz_stream s) {
+    return vz_launch_linear(mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, act, out_fp32), (hipStream_t)s);
+}
+extern "C" int vz_op_linear_impl(int impl, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N,
+                                 int K, const float* bias, const void* residual, int ldr, int act, int out_fp32,
+                                 vz_stream s) {
+    LinearArgs a = mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, act, out_fp32);
+    if (impl == 0) return vz_launch_gemm(a, (hipStream_t)s);
+    if (impl == 1) return vz_launch_gemv(a, (hipStream_t)s);
+    vz_set_error("linear: unknown impl %d", impl);
+    return VZ_ERR_ARG;
+}
+extern "C" int vz_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* w, const float* b, int rows, int cols,
+                               float eps, vz_stream s) {
+    return vz_launch_layernorm((const bf16_t*)x, ldx, (bf16_t*)y, ldy, w, b, rows, cols, eps, (hipStream_t)s);
+}
+extern "C" int vz_op_rmsnorm(const void* x, int ldx, void* y, int ldy, const float* w, int rows, int cols, float eps,
+                             vz_stream s) {
+    return vz_launch_rmsnorm((const bf16_t*)x, ldx, (bf16_t*)y, ldy, w, rows, cols, eps, (hipStream_t)s);
+}
+extern "C" int vz_op_attention(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int Hq, int Hkv,
+                               int head_dim, long q_bs, long q_ss, long q_hs, long k_bs, long k_ss, long k_hs, long v_bs,
+                               long v_ss, long v_hs, long o_bs, long o_ss, long o_hs, float scale, int causal, int q_pos0,
+                               int window, const int* kv_len, vz_stream s) {
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o;
+    a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = Hq; a.Hkv = Hkv; a.head_dim = head_dim;
+    a.q_bs = q_bs; a.q_ss = q_ss; a.q_hs = q_hs; a.k_bs = k_bs; a.k_ss = k_ss; a.k_hs = k_hs;
+    a.v_bs = v_bs; a.v_ss = v_ss; a.v_hs = v_hs; a.o_bs = o_bs; a.o_ss = o_ss; a.o_hs = o_hs;
+    a.scale = scale; a.causal = causal; a.q_pos0 = q_pos0; a.window = window; a.kv_len = kv_len;
+    return vz_launch_attention(a, (hipStream_t)s);
+}
+extern "C" int vz_op_rope_kv(const void* qkv, int ld, void* q_out, void* kc, void* vc, const float* cosT, const float* sinT,
+                             const int* pos, const int* slot, int B, int S, int Hq, int Hkv, int D, int max_ctx, vz_stream s) {
+    VZ_CHECK_ARG(qkv && q_out && kc && vc && cosT && sinT && pos && slot && B > 0 && S > 0, "rope: bad argument");
+    return vz_launch_rope_kv((const bf16_t*)qkv, ld, (bf16_t*)q_out, (bf16_t*)kc, (bf16_t*)vc, cosT, sinT, pos, slot, B, S, Hq,
+                             Hkv, D, max_ctx, (hipStream_t)s);
+}
+extern "C" int vz_op_attention_decode(const void* q, const void* kc, const void* vc, void* o, float* ws, int B, int Hq, int Hkv,
+                                      int D, int max_ctx, int nsplit, int window, float scale, const int* ctx_len, vz_stream s) {
+    VZ_CHECK_ARG(q && kc && vc && o && ws && ctx_len && B > 0, "attention_decode: bad argument");
+    AttnDecodeArgs a;
+    a.q = (const bf16_t*)q; a.kc = (const bf16_t*)kc; a.vc = (const bf16_t*)vc; a.o = (bf16_t*)o; a.part = ws;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_ctx = max_ctx; a.nsplit = nsplit; a.window = window; a.scale = scale;
+    a.ctx_len = ctx_len;
+    return vz_launch_attn_decode(a, (hipStream_t)s);
+}
+extern "C" int vz_op_argmax(const float* logits, int rows, int cols, int* ids, vz_stream s) {
+    return vz_launch_argmax(logits, rows, cols, ids, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (hipStream_t)s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------------
+struct Weight { const void* p; int dtype; long n; };
+
+enum { K_GEMM = 0, K_GEMV = 1, K_ATTN = 2, K_ATTN_DEC = 3, K_NORM = 4, K_OTHER = 5 };
+
+struct vz_engine {
+    vz_config c;
+    std::unordered_map<std::string, Weight> w;
+    bool finalized = false;
+    // rope
+    const float* cosT = nullptr; const float* sinT = nullptr; int rope_max = 0;
+    // workspace (one arena, carved per stage; stages never overlap in time on a stream)
+    char* arena = nullptr; size_t arena_bytes = 0;
+    // kv cache: [layer][2][B][Hkv][max_ctx][D]
+    bf16_t* kv = nullptr; size_t kv_layer_elems = 0;
+    // decode state (device)
+    int* d_state = nullptr;  // [cur_ids[B] | pos[B] | slot[B] | len[B] | step]
+    int dec_B = 0;
+    float* d_logits = nullptr;   // [max_batch, vocab] fp32
+    float* d_part = nullptr;     // decode attention partials
+    int nsplit = 16;
+    hipStream_t cap_stream = nullptr;   // stream capture is not allowed on the legacy null stream torch hands us
+    hipGraphExec_t dec_graph = nullptr; int dec_graph_B = 0, dec_graph_n = 0; int* dec_graph_out = nullptr; char* dec_graph_arena = nullptr;
+    int* h_pinned = nullptr;     // pinned staging for small host->device uploads
+    size_t h_pinned_ints = 0;
+    // profiling
+    int prof_on = 0, prof_class = -1;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev; size_t prof_used = 0;
+};
+
+static const void* W_(vz_engine* e, const std::string& name, int dtype, long n, int* rc) {
+    auto it = e->w.find(name);
+    if (it == e->w.end()) { vz_set_error("weight '%s' was never registered", name.c_str()); *rc = VZ_ERR_STATE; return nullptr; }
+    if (it->second.dtype != dtype || it->second.n != n) {
+        vz_set_error("weight '%s': expected dtype %d n %ld, got dtype %d n %ld", name.c_str(), dtype, n, it->second.dtype,
+                     it->second.n);
+        *rc = VZ_ERR_STATE;
+        return nullptr;
+    }
+    return it->second.p;
+}
+#define WB(name, n) ((const bf16_t*)W_(e, name, 0, (long)(n), &rc))
+#define WF(name, n) ((const float*)W_(e, name, 1, (long)(n), &rc))
+#define RC(expr) do { int _r = (expr); if (_r) return _r; } while (0)
+
+struct ProfScope {
+    vz_engine* e; hipStream_t s; bool on; size_t idx;
+    ProfScope(vz_engine* e_, int klass, hipStream_t s_) : e(e_), s(s_), on(false), idx(0) {
+        if (e->prof_on && klass == e->prof_class) {
+            if (e->prof_used == e->prof_ev.size()) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+                e->prof_ev.push_back({a, b});
+            }
+            idx = e->prof_used++;
+            on = true;
+            hipEventRecord(e->prof_ev[idx].first, s);
+        }
+    }
+    ~ProfScope() { if (on) hipEventRecord(e->prof_ev[idx].second, s); }
+};
+
+static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M,
+                  int N, int K, const float* bias, const bf16_t* res, int ldr, int act, int out_fp32, hipStream_t s,
+                  const float* norm_w = nullptr, float norm_eps = 0.f) {
+    LinearArgs a = mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, res, ldr, act, out_fp32);
+    a.norm_w = norm_w; a.norm_eps = norm_eps;
+    if (norm_w) { ProfScope ps(e, K_GEMV, s); return vz_launch_gemv(a, s); }
+    const bool gemv = M <= 8 && (K % 512) == 0 && (size_t)(M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8) * K * 2 + 64 <= 65536;
+    ProfScope ps(e, gemv ? K_GEMV : K_GEMM, s);
+    (void)klass_hint;
+    return vz_launch_linear(a, s);
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {
+    char* base; size_t off, cap; bool ok;
+    Carver(char* b, size_t c) : base(b), off(0), cap(c), ok(true) {}
+    template <typename T> T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = (T*)(base + off);
+        off += n * sizeof(T);
+        if (off > cap) ok = false;
+        return p;
+    }
+};
+
+static int ensure_arena(vz_engine* e, size_t bytes) {
+    if (bytes <= e->arena_bytes) return VZ_OK;
+    if (e->arena) { VZ_CHECK_HIP(hipDeviceSynchronize()); VZ_CHECK_HIP(hipFree(e->arena)); e->arena = nullptr; e->arena_bytes = 0; }
+    VZ_CHECK_HIP(hipMalloc((void**)&e->arena, bytes));
+    e->arena_bytes = bytes;
+    return VZ_OK;
+}
+
+static int upload_ints(vz_engine* e, const int* h, size_t n, int* d, hipStream_t s) {
+    // small host arrays go through a pinned staging buffer; the copy is enqueued on the stream
+    if (n > e->h_pinned_ints) {
+        if (e->h_pinned) { VZ_CHECK_HIP(hipStreamSynchronize(s)); VZ_CHECK_HIP(hipHostFree(e->h_pinned)); }
+        VZ_CHECK_HIP(hipHostMalloc((void**)&e->h_pinned, n * sizeof(int)));
+        e->h_pinned_ints = n;
+    } else {
+        VZ_CHECK_HIP(hipStreamSynchronize(s));  // previous use of the staging buffer has drained
+    }
+    memcpy(e->h_pinned, h, n * sizeof(int));
+    VZ_CHECK_HIP(hipMemcpyAsync(d, e->h_pinned, n * sizeof(int), hipMemcpyHostToDevice, s));
+    return VZ_OK;
+}
+
+extern "C" int vz_engine_create(const vz_config* cfg, vz_engine** out) {
+    VZ_CHECK_ARG(cfg && out, "engine_create: null argument");
+    const vz_config& c = *cfg;
+    VZ_CHECK_ARG(c.head_dim == 128 && c.hidden % 512 == 0 && c.inter % 512 == 0 && c.n_heads % c.n_kv_heads == 0 &&
+                     c.n_heads * c.head_dim == c.hidden, "engine_create: unsupported Zephyr geometry");
+    VZ_CHECK_ARG(c.clip_hidden % 512 == 0 && c.clip_hidden / c.clip_heads == 64 && c.clip_image % c.clip_patch == 0,
+                 "engine_create: unsupported CLIP geometry");
+    VZ_CHECK_ARG(c.hidden / c.qf_heads == 512 && c.qf_kv_dim == (c.fusion_groups + 1) * c.clip_hidden && c.qf_queries == 32,
+                 "engine_create: unsupported Q-Former geometry");
+    VZ_CHECK_ARG(c.clip_layers + 1 >= c.fusion_groups * c.fusion_layers_per_group + 1, "engine_create: CLIP too shallow for the fusion");
+    VZ_CHECK_ARG(c.max_batch >= 1 && c.max_ctx >= 64 && c.max_tiles >= 1 && c.max_text >= 0, "engine_create: bad capacity");
+    VZ_CHECK_ARG(c.tp_size == 1 && c.tp_rank == 0, "engine_create: tensor parallel engine not built in this version");
+    { int r = vz_init_gemm_kernels(); if (r) return r; r = vz_init_attention_kernels(); if (r) return r; }
+    vz_engine* e = new vz_engine();
+    e->c = c;
+    e->kv_layer_elems = (size_t)2 * c.max_batch * c.n_kv_heads * c.max_ctx * c.head_dim;
+    hipError_t er = hipMalloc((void**)&e->kv, e->kv_layer_elems * c.n_layers * sizeof(bf16_t));
+    if (er == hipSuccess) er = hipMalloc((void**)&e->d_state, (4 * c.max_batch + 4) * sizeof(int));
+    if (er == hipSuccess) er = hipMalloc((void**)&e->d_logits, (size_t)c.max_batch * c.vocab * sizeof(float));
+    if (er == hipSuccess) er = hipMalloc((void**)&e->d_part, (size_t)c.max_batch * c.n_heads * 64 * (128 + 2) * sizeof(float));
+    if (er != hipSuccess) {
+        vz_set_error("engine_create: hipMalloc failed: %s", hipGetErrorString(er));
+        delete e;
+        return VZ_ERR_HIP;
+    }
+    *out = e;
+    return VZ_OK;
+}
+
+extern "C" int vz_engine_destroy(vz_engine* e) {
+    if (!e) return VZ_OK;
+    hipDeviceSynchronize();
+    if (e->dec_graph) (void)hipGraphExecDestroy(e->dec_graph);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    for (auto& p : e->prof_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (e->arena) hipFree(e->arena);
+    if (e->kv) hipFree(e->kv);
+    if (e->d_state) hipFree(e->d_state);
+    if (e->d_logits) hipFree(e->d_logits);
+    if (e->d_part) hipFree(e->d_part);
+    if (e->h_pinned) hipHostFree(e->h_pinned);
+    delete e;
+    return VZ_OK;
+}
+
+extern "C" int vz_engine_set_weight(vz_engine* e, const char* name, const void* d_ptr, int dtype, long n_elems) {
+    VZ_CHECK_ARG(e && name && d_ptr && (dtype == 0 || dtype == 1) && n_elems > 0, "set_weight: bad argument");
+    VZ_CHECK_ARG(((uintptr_t)d_ptr & 15) == 0, "set_weight: '%s' must be 16-byte aligned", name);
+    e->w[name] = Weight{d_ptr, dtype, n_elems};
+    e->finalized = false;
+    return VZ_OK;
+}
+
+static int kpad_patch(const vz_config& c) { return (int)align_up((size_t)3 * c.clip_patch * c.clip_patch, 64); }
+
+extern "C" int vz_engine_finalize(vz_engine* e) {
+    VZ_CHECK_ARG(e, "finalize: null engine");
+    const vz_config& c = e->c;
+    int rc = VZ_OK;
+    const long C = c.clip_hidden, H = c.hidden, tokens = (c.clip_image / c.clip_patch) * (c.clip_image / c.clip_patch) + 1;
+    WB("clip.patch_w", C * kpad_patch(c)); WB("clip.cls", C); WB("clip.pos", tokens * C);
+    WF("clip.pre_ln.w", C); WF("clip.pre_ln.b", C);
+    for (int i = 0; i < c.clip_layers && !rc; ++i) {
+        const std::string p = "clip." + std::to_string(i) + ".";
+        WF(p + "ln1.w", C); WF(p + "ln1.b", C); WB(p + "qkv.w", 3 * C * C); WF(p + "qkv.b", 3 * C);
+        WB(p + "o.w", C * C); WF(p + "o.b", C); WF(p + "ln2.w", C); WF(p + "ln2.b", C);
+        WB(p + "fc1.w", (long)c.clip_inter * C); WF(p + "fc1.b", c.clip_inter);
+        WB(p + "fc2.w", (long)c.clip_inter * C); WF(p + "fc2.b", C);
+    }
+    WB("qf.queries", (long)c.qf_queries * H); WF("qf.pre_norm.w", c.qf_kv_dim); WF("qf.pre_norm.b", c.qf_kv_dim);
+    WF("qf.norm.w", H); WF("qf.norm.b", H);
+    for (int i = 0; i < c.qf_blocks && !rc; ++i) {
+        const std::string p = "qf." + std::to_string(i) + ".";
+        for (const char* n : {"n1", "n2", "n3"}) { WF(p + n + ".w", H); WF(p + n + ".b", H); }
+        WB(p + "sa_in.w", 3 * H * H); WF(p + "sa_in.b", 3 * H); WB(p + "sa_out.w", H * H); WF(p + "sa_out.b", H);
+        WB(p + "ca_q.w", H * H); WF(p + "ca_q.b", H); WB(p + "ca_kv.w", 2 * H * c.qf_kv_dim); WF(p + "ca_kv.b", 2 * H);
+        WB(p + "ca_out.w", H * H); WF(p + "ca_out.b", H);
+        WB(p + "ffn1.w", 2 * H * H); WF(p + "ffn1.b", 2 * H); WB(p + "ffn2.w", 2 * H * H); WF(p + "ffn2.b", H);
+    }
+    const long qkv_n = (long)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
+    WB("llm.embed", (long)c.vocab * H); WF("llm.norm", H); WB("llm.lm_head", (long)c.vocab * H);
+    for (int i = 0; i < c.n_layers && !rc; ++i) {
+        const std::string p = "llm." + std::to_string(i) + ".";
+        WF(p + "in_norm", H); WF(p + "post_norm", H); WB(p + "qkv.w", qkv_n * H); WB(p + "o.w", H * H);
+        WB(p + "gu.w", 2L * c.inter * H); WB(p + "down.w", (long)c.inter * H);
+    }
+    if (rc) return rc;
+    e->finalized = true;
+    return VZ_OK;
+}
+
+extern "C" int vz_engine_set_rope(vz_engine* e, const float* d_cos, const float* d_sin, int max_pos) {
+    VZ_CHECK_ARG(e && d_cos && d_sin && max_pos > 0, "set_rope: bad argument");
+    e->cosT = d_cos; e->sinT = d_sin; e->rope_max = max_pos;
+    return VZ_OK;
+}
+
+#define NEED_READY()                                                                                         \
+    do {                                                                                                     \
+        if (!e || !e->finalized) { vz_set_error("engine not finalized (register every weight, then vz_engine_finalize)"); return VZ_ERR_STATE; } \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// a8-a10: CLIP tower + fusion
+// ------------------------------------------------------------------------------------------------
+extern "C" int vz_clip_fused_features(vz_engine* e, const void* d_images, int T, void* d_out, void* d_hidden_dbg,
+                                      vz_stream stream) {
+    NEED_READY();
+    const vz_config& c = e->c;
+    hipStream_t s = (hipStream_t)stream;
+    VZ_CHECK_ARG(d_images && d_out && T >= 1 && T <= c.max_tiles, "clip: T=%d outside [1,%d]", T, c.max_tiles);
+    const int C = c.clip_hidden, g = c.clip_image / c.clip_patch, P = g * g, tokens = P + 1, kpad = kpad_patch(c);
+    const int L = c.clip_layers, rows = T * tokens;
+    const size_t hs_layer = (size_t)rows * C;
+    size_t need = 0;
+    {
+        Carver m(nullptr, ~(size_t)0);
+        m.take<bf16_t>((size_t)T * P * kpad); m.take<bf16_t>((size_t)T * P * C);
+        if (!d_hidden_dbg) m.take<bf16_t>(hs_layer * (L + 1));
+        m.take<bf16_t>(hs_layer); m.take<bf16_t>(hs_layer * 3); m.take<bf16_t>(hs_layer); m.take<bf16_t>((size_t)rows * c.clip_inter);
+        need = m.off + 256;
+    }
+    RC(ensure_arena(e, need));
+    Carver m(e->arena, e->arena_bytes);
+    bf16_t* col = m.take<bf16_t>((size_t)T * P * kpad);
+    bf16_t* pe = m.take<bf16_t>((size_t)T * P * C);
+    bf16_t* hs = d_hidden_dbg ? (bf16_t*)d_hidden_dbg : m.take<bf16_t>(hs_layer * (L + 1));
+    bf16_t* y = m.take<bf16_t>(hs_layer);
+    bf16_t* qkv = m.take<bf16_t>(hs_layer * 3);
+    bf16_t* att = m.take<bf16_t>(hs_layer);
+    bf16_t* mlp = m.take<bf16_t>((size_t)rows * c.clip_inter);
+    int rc = VZ_OK;
+    {
+        ProfScope ps(e, K_OTHER, s);
+        RC(vz_launch_im2col((const bf16_t*)d_images, T, c.clip_image, c.clip_patch, kpad, col, s));
+    }
+    RC(linear(e, 0, col, kpad, WB("clip.patch_w", (long)C * kpad), kpad, pe, C, T * P, C, kpad, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s));
+    {
+        ProfScope ps(e, K_OTHER, s);
+        RC(vz_launch_clip_assemble(pe, WB("clip.cls", C), WB("clip.pos", (long)tokens * C), T, tokens, C, att, s));
+    }
+    {
+        ProfScope ps(e, K_NORM, s);
+        RC(vz_launch_layernorm(att, C, hs, C, WF("clip.pre_ln.w", C), WF("clip.pre_ln.b", C), rows, C, c.clip_eps, s));
+    }
+    for (int i = 0; i < L; ++i) {
+        const std::string p = "clip." + std::to_string(i) + ".";
+        bf16_t* x = hs + hs_layer * i;
+        bf16_t* xn = hs + hs_layer * (i + 1);
+        { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(x, C, y, C, WF(p + "ln1.w", C), WF(p + "ln1.b", C), rows, C, c.clip_eps, s)); }
+        RC(linear(e, 0, y, C, WB(p + "qkv.w", 3L * C * C), C, qkv, 3 * C, rows, 3 * C, C, WF(p + "qkv.b", 3 * C), nullptr, 0, VZ_ACT_NONE, 0, s));
+        {
+            ProfScope ps(e, K_ATTN, s);
+            AttnArgs a;
+            a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.o = att;
+            a.B = T; a.Sq = tokens; a.Sk = tokens; a.Hq = c.clip_heads; a.Hkv = c.clip_heads; a.head_dim = 64;
+            a.q_bs = a.k_bs = a.v_bs = (long)tokens * 3 * C; a.q_ss = a.k_ss = a.v_ss = 3 * C; a.q_hs = a.k_hs = a.v_hs = 64;
+            a.o_bs = (long)tokens * C; a.o_ss = C; a.o_hs = 64;
+            a.scale = 0.125f; a.causal = 0; a.q_pos0 = 0; a.window = 0; a.kv_len = nullptr;
+            RC(vz_launch_attention(a, s));
+        }
+        RC(linear(e, 0, att, C, WB(p + "o.w", (long)C * C), C, xn, C, rows, C, C, WF(p + "o.b", C), x, C, VZ_ACT_NONE, 0, s));
+        { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(xn, C, y, C, WF(p + "ln2.w", C), WF(p + "ln2.b", C), rows, C, c.clip_eps, s)); }
+        RC(linear(e, 0, y, C, WB(p + "fc1.w", (long)c.clip_inter * C), C, mlp, c.clip_inter, rows, c.clip_inter, C,
+                  WF(p + "fc1.b", c.clip_inter), nullptr, 0, VZ_ACT_QUICK_GELU, 0, s));
+        RC(linear(e, 0, mlp, c.clip_inter, WB(p + "fc2.w", (long)c.clip_inter * C), c.clip_inter, xn, C, rows, C, c.clip_inter,
+                  WF(p + "fc2.b", C), xn, C, VZ_ACT_NONE, 0, s));
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(e, K_OTHER, s);
+        const int first = L - c.fusion_groups * c.fusion_layers_per_group;
+        RC(vz_launch_fusion(hs, (long)hs_layer, first, c.fusion_groups, c.fusion_layers_per_group, T, tokens, C, (bf16_t*)d_out, s));
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a11: Q-Former
+// ------------------------------------------------------------------------------------------------
+static int qf_attn(vz_engine* e, const bf16_t* q, long q_bs, long q_ss, const bf16_t* k, const bf16_t* v, long kv_bs, long kv_ss,
+                   bf16_t* o, int B, int Sq, int Sk, hipStream_t s) {
+    ProfScope ps(e, K_ATTN, s);
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = o;
+    a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = e->c.qf_heads; a.Hkv = e->c.qf_heads; a.head_dim = 512;
+    a.q_bs = q_bs; a.q_ss = q_ss; a.q_hs = 512; a.k_bs = a.v_bs = kv_bs; a.k_ss = a.v_ss = kv_ss; a.k_hs = a.v_hs = 512;
+    a.o_bs = (long)Sq * e->c.hidden; a.o_ss = e->c.hidden; a.o_hs = 512;
+    a.scale = 0.044194173824159216f;  // 512^-0.5
+    a.causal = 0; a.q_pos0 = 0; a.window = 0; a.kv_len = nullptr;
+    return vz_launch_attention(a, s);
+}
+
+extern "C" int vz_qformer(vz_engine* e, const void* d_feats, int T, const void* d_text, int n_samples, int Lmax,
+                          const int* h_tile_sample, void* d_out, vz_stream stream) {
+    NEED_READY();
+    const vz_config& c = e->c;
+    hipStream_t s = (hipStream_t)stream;
+    VZ_CHECK_ARG(d_feats && d_out && T >= 1 && T <= c.max_tiles, "qformer: T=%d outside [1,%d]", T, c.max_tiles);
+    VZ_CHECK_ARG(Lmax >= 0 && Lmax <= c.max_text, "qformer: Lmax=%d outside [0,%d]", Lmax, c.max_text);
+    VZ_CHECK_ARG(n_samples >= 1 && n_samples <= T && h_tile_sample && (Lmax == 0 || d_text), "qformer: bad sample map");
+    for (int t = 0; t < T; ++t) VZ_CHECK_ARG(h_tile_sample[t] >= 0 && h_tile_sample[t] < n_samples, "qformer: tile_sample[%d] out of range", t);
+    const int H = c.hidden, NQ = c.qf_queries, KD = c.qf_kv_dim, P = (c.clip_image / c.clip_patch) * (c.clip_image / c.clip_patch);
+    const int N0 = NQ + Lmax, FF = 2 * H;
+    const size_t R = (size_t)T * NQ;  // query rows in flight after block 0's self-attention
+    size_t need;
+    {
+        Carver m(nullptr, ~(size_t)0);
+        m.take<bf16_t>((size_t)T * P * KD); m.take<bf16_t>((size_t)T * P * 2 * H);
+        m.take<bf16_t>((size_t)n_samples * N0 * H); m.take<bf16_t>((size_t)n_samples * N0 * H); m.take<bf16_t>((size_t)n_samples * N0 * 2 * H);
+        m.take<bf16_t>((size_t)NQ * H); m.take<bf16_t>((size_t)n_samples * NQ * H); m.take<bf16_t>((size_t)n_samples * NQ * H);
+        m.take<bf16_t>(R * H); m.take<bf16_t>(R * H); m.take<bf16_t>(R * 3 * H); m.take<bf16_t>(R * H); m.take<bf16_t>(R * FF);
+        need = m.off + 256;
+    }
+    RC(ensure_arena(e, need));
+    Carver m(e->arena, e->arena_bytes);
+    bf16_t* fn = m.take<bf16_t>((size_t)T * P * KD);            // pre_norm(features)
+    bf16_t* ckv = m.take<bf16_t>((size_t)T * P * 2 * H);        // cross-attention K|V of the current block
+    bf16_t* x0 = m.take<bf16_t>((size_t)n_samples * N0 * H);    // [queries ; text] per sample
+    bf16_t* y0 = m.take<bf16_t>((size_t)n_samples * N0 * H);
+    bf16_t* kv0 = m.take<bf16_t>((size_t)n_samples * N0 * 2 * H);
+    bf16_t* q0 = m.take<bf16_t>((size_t)NQ * H);
+    bf16_t* a0 = m.take<bf16_t>((size_t)n_samples * NQ * H);
+    bf16_t* xs = m.take<bf16_t>((size_t)n_samples * NQ * H);
+    bf16_t* x = m.take<bf16_t>(R * H);
+    bf16_t* y = m.take<bf16_t>(R * H);
+    bf16_t* qkv = m.take<bf16_t>(R * 3 * H);
+    bf16_t* att = m.take<bf16_t>(R * H);
+    bf16_t* ff = m.take<bf16_t>(R * FF);
+    int rc = VZ_OK;
+    { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm((const bf16_t*)d_feats, KD, fn, KD, WF("qf.pre_norm.w", KD), WF("qf.pre_norm.b", KD), T * P, KD, c.qf_eps, s)); }
+    const bf16_t* queries = WB("qf.queries", (long)NQ * H);
+    if (rc) return rc;
+    // ---- block 0 self-attention, once per sample, query rows only ----
+    {
+        ProfScope ps(e, K_OTHER, s);
+        for (int sm = 0; sm < n_samples; ++sm) {
+            RC(vz_launch_copy_rows(queries, H, x0 + (size_t)sm * N0 * H, H, NQ, H, s));
+            if (Lmax > 0) RC(vz_launch_copy_rows((const bf16_t*)d_text + (size_t)sm * Lmax * H, H, x0 + ((size_t)sm * N0 + NQ) * H, H, Lmax, H, s));
+            RC(vz_launch_copy_rows(queries, H, xs + (size_t)sm * NQ * H, H, NQ, H, s));
+        }
+    }
+    {
+        const std::string p = "qf.0.";
+        const bf16_t* w_in = WB(p + "sa_in.w", 3L * H * H);
+        const float* b_in = WF(p + "sa_in.b", 3 * H);
+        if (rc) return rc;
+        { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(x0, H, y0, H, WF(p + "n1.w", H), WF(p + "n1.b", H), n_samples * N0, H, c.qf_eps, s)); }
+        RC(linear(e, 0, y0, H, w_in + (size_t)H * H, H, kv0, 2 * H, n_samples * N0, 2 * H, H, b_in + H, nullptr, 0, VZ_ACT_NONE, 0, s));
+        RC(linear(e, 0, y0, H, w_in, H, q0, H, NQ, H, H, b_in, nullptr, 0, VZ_ACT_NONE, 0, s));  // rows 0..31 of sample 0 = LN1(queries)
+        RC(qf_attn(e, q0, 0, H, kv0, kv0 + H, (long)N0 * 2 * H, 2 * H, a0, n_samples, NQ, N0, s));
+        RC(linear(e, 0, a0, H, WB(p + "sa_out.w", (long)H * H), H, xs, H, n_samples * NQ, H, H, WF(p + "sa_out.b", H), xs, H, VZ_ACT_NONE, 0, s));
+        ProfScope ps(e, K_OTHER, s);
+        for (int t = 0; t < T; ++t) RC(vz_launch_copy_rows(xs + (size_t)h_tile_sample[t] * NQ * H, H, x + (size_t)t * NQ * H, H, NQ, H, s));
+    }
+    for (int i = 0; i < c.qf_blocks; ++i) {
+        const std::string p = "qf." + std::to_string(i) + ".";
+        if (i > 0) {
+            { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(x, H, y, H, WF(p + "n1.w", H), WF(p + "n1.b", H), (int)R, H, c.qf_eps, s)); }
+            RC(linear(e, 0, y, H, WB(p + "sa_in.w", 3L * H * H), H, qkv, 3 * H, (int)R, 3 * H, H, WF(p + "sa_in.b", 3 * H), nullptr, 0, VZ_ACT_NONE, 0, s));
+            RC(qf_attn(e, qkv, (long)NQ * 3 * H, 3 * H, qkv + H, qkv + 2 * H, (long)NQ * 3 * H, 3 * H, att, T, NQ, NQ, s));
+            RC(linear(e, 0, att, H, WB(p + "sa_out.w", (long)H * H), H, x, H, (int)R, H, H, WF(p + "sa_out.b", H), x, H, VZ_ACT_NONE, 0, s));
+        }
+        // cross-attention against the tile's 576 fused visual tokens
+        RC(linear(e, 0, fn, KD, WB(p + "ca_kv.w", 2L * H * KD), KD, ckv, 2 * H, T * P, 2 * H, KD, WF(p + "ca_kv.b", 2 * H), nullptr, 0, VZ_ACT_NONE, 0, s));
+        { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(x, H, y, H, WF(p + "n2.w", H), WF(p + "n2.b", H), (int)R, H, c.qf_eps, s)); }
+        RC(linear(e, 0, y, H, WB(p + "ca_q.w", (long)H * H), H, qkv, H, (int)R, H, H, WF(p + "ca_q.b", H), nullptr, 0, VZ_ACT_NONE, 0, s));
+        RC(qf_attn(e, qkv, (long)NQ * H, H, ckv, ckv + H, (long)P * 2 * H, 2 * H, att, T, NQ, P, s));
+        RC(linear(e, 0, att, H, WB(p + "ca_out.w", (long)H * H), H, x, H, (int)R, H, H, WF(p + "ca_out.b", H), x, H, VZ_ACT_NONE, 0, s));
+        // FFN
+        { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(x, H, y, H, WF(p + "n3.w", H), WF(p + "n3.b", H), (int)R, H, c.qf_eps, s)); }
+        RC(linear(e, 0, y, H, WB(p + "ffn1.w", 2L * H * H), H, ff, FF, (int)R, FF, H, WF(p + "ffn1.b", FF), nullptr, 0, VZ_ACT_GELU_ERF, 0, s));
+        RC(linear(e, 0, ff, FF, WB(p + "ffn2.w", 2L * H * H), FF, x, H, (int)R, H, FF, WF(p + "ffn2.b", H), x, H, VZ_ACT_NONE, 0, s));
+        if (rc) return rc;
+    }
+    { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(x, H, (bf16_t*)d_out, H, WF("qf.norm.w", H), WF("qf.norm.b", H), (int)R, H, c.qf_eps, s)); }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a6/a7: splice
+// ------------------------------------------------------------------------------------------------
+extern "C" int vz_embed_splice(vz_engine* e, const int* d_kind, const int* d_idx, int rows, const void* d_visual, void* d_out,
+                               vz_stream stream) {
+    NEED_READY();
+    int rc = VZ_OK;
+    const bf16_t* table = WB("llm.embed", (long)e->c.vocab * e->c.hidden);
+    if (rc) return rc;
+    VZ_CHECK_ARG(d_idx && d_out && rows > 0, "splice: bad argument");
+    ProfScope ps(e, K_OTHER, (hipStream_t)stream);
+    return vz_launch_gather_rows(d_kind, d_idx, rows, e->c.hidden, table, (const bf16_t*)d_visual, (bf16_t*)d_out, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a12: Zephyr prefill
+// ------------------------------------------------------------------------------------------------
+static bf16_t* kc_of(vz_engine* e, int layer) { return e->kv + (size_t)layer * e->kv_layer_elems; }
+static bf16_t* vc_of(vz_engine* e, int layer) { return kc_of(e, layer) + e->kv_layer_elems / 2; }
+
+extern "C" int vz_llm_prefill(vz_engine* e, const void* d_embeds, int B, int S, const int* h_seqlens, const int* d_pos,
+                              float* d_logits_all, float* d_logits_last, vz_stream stream) {
+    NEED_READY();
+    const vz_config& c = e->c;
+    hipStream_t s = (hipStream_t)stream;
+    VZ_CHECK_ARG(d_embeds && h_seqlens && d_pos && B >= 1 && B <= c.max_batch && S >= 1 && S <= c.max_ctx,
+                 "prefill: B=%d S=%d outside capacity (max_batch %d, max_ctx %d)", B, S, c.max_batch, c.max_ctx);
+    VZ_CHECK_ARG(e->cosT && e->rope_max >= c.max_ctx, "prefill: rotary tables not set or shorter than max_ctx");
+    for (int b = 0; b < B; ++b) VZ_CHECK_ARG(h_seqlens[b] >= 1 && h_seqlens[b] <= S, "prefill: seqlen[%d]=%d outside [1,%d]", b, h_seqlens[b], S);
+    const int H = c.hidden, D = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads, QKV = (Hq + 2 * Hkv) * D, I = c.inter;
+    const int rows = B * S;
+    size_t need;
+    {
+        Carver m(nullptr, ~(size_t)0);
+        m.take<bf16_t>((size_t)rows * H); m.take<bf16_t>((size_t)rows * H); m.take<bf16_t>((size_t)rows * QKV); m.take<bf16_t>((size_t)rows * H);
+        m.take<bf16_t>((size_t)rows * H); m.take<bf16_t>((size_t)rows * I); m.take<int>(rows + B + 16); m.take<bf16_t>((size_t)B * H * 2);
+        need = m.off + 256;
+    }
+    RC(ensure_arena(e, need));
+    Carver m(e->arena, e->arena_bytes);
+    bf16_t* x = m.take<bf16_t>((size_t)rows * H);
+    bf16_t* y = m.take<bf16_t>((size_t)rows * H);
+    bf16_t* qkv = m.take<bf16_t>((size_t)rows * QKV);
+    bf16_t* q = m.take<bf16_t>((size_t)rows * H);
+    bf16_t* att = m.take<bf16_t>((size_t)rows * H);
+    bf16_t* act = m.take<bf16_t>((size_t)rows * I);
+    int* d_ints = m.take<int>(rows + B + 16);   // slot[rows] | seqlens[B]
+    bf16_t* ylast = m.take<bf16_t>((size_t)B * H * 2);
+    int* d_slot = d_ints;
+    int* d_len = d_ints + rows;
+    {
+        std::vector<int> h(rows + B);
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < S; ++t) h[b * S + t] = t < h_seqlens[b] ? t : -1;
+        for (int b = 0; b < B; ++b) h[rows + b] = h_seqlens[b];
+        RC(upload_ints(e, h.data(), h.size(), d_ints, s));
+    }
+    int rc = VZ_OK;
+    { ProfScope ps(e, K_OTHER, s); RC(vz_launch_copy_rows((const bf16_t*)d_embeds, H, x, H, rows, H, s)); }
+    for (int i = 0; i < c.n_layers; ++i) {
+        const std::string p = "llm." + std::to_string(i) + ".";
+        { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(x, H, y, H, WF(p + "in_norm", H), rows, H, c.rms_eps, s)); }
+        RC(linear(e, 0, y, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, rows, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s));
+        { ProfScope ps(e, K_OTHER, s); RC(vz_launch_rope_kv(qkv, QKV, q, kc_of(e, i), vc_of(e, i), e->cosT, e->sinT, d_pos, d_slot, B, S, Hq, Hkv, D, c.max_ctx, s)); }
+        {
+            ProfScope ps(e, K_ATTN, s);
+            AttnArgs a;
+            a.q = q; a.k = kc_of(e, i); a.v = vc_of(e, i); a.o = att;
+            a.B = B; a.Sq = S; a.Sk = S; a.Hq = Hq; a.Hkv = Hkv; a.head_dim = D;
+            a.q_bs = (long)S * H; a.q_ss = H; a.q_hs = D;
+            a.k_bs = a.v_bs = (long)Hkv * c.max_ctx * D; a.k_ss = a.v_ss = D; a.k_hs = a.v_hs = (long)c.max_ctx * D;
+            a.o_bs = (long)S * H; a.o_ss = H; a.o_hs = D;
+            a.scale = 0.08838834764831845f;  // 128^-0.5
+            a.causal = 1; a.q_pos0 = 0; a.window = c.sliding_window; a.kv_len = d_len;
+            RC(vz_launch_attention(a, s));
+        }
+        RC(linear(e, 0, att, H, WB(p + "o.w", (long)H * H), H, x, H, rows, H, H, nullptr, x, H, VZ_ACT_NONE, 0, s));
+        { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(x, H, y, H, WF(p + "post_norm", H), rows, H, c.rms_eps, s)); }
+        RC(linear(e, 0, y, H, WB(p + "gu.w", 2L * I * H), H, act, I, rows, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s));
+        RC(linear(e, 0, act, I, WB(p + "down.w", (long)I * H), I, x, H, rows, H, I, nullptr, x, H, VZ_ACT_NONE, 0, s));
+        if (rc) return rc;
+    }
+    const bf16_t* lm = WB("llm.lm_head", (long)c.vocab * H);
+    const float* fn = WF("llm.norm", H);
+    if (rc) return rc;
+    if (d_logits_all) {
+        { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(x, H, y, H, fn, rows, H, c.rms_eps, s)); }
+        RC(linear(e, 0, y, H, lm, H, d_logits_all, c.vocab, rows, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s));
+    }
+    if (d_logits_last) {
+        {
+            ProfScope ps(e, K_OTHER, s);
+            for (int b = 0; b < B; ++b) RC(vz_launch_copy_rows(x + ((size_t)b * S + h_seqlens[b] - 1) * H, H, ylast + (size_t)b * H, H, 1, H, s));
+        }
+        { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(ylast, H, ylast + (size_t)B * H, H, fn, B, H, c.rms_eps, s)); }
+        RC(linear(e, 0, ylast + (size_t)B * H, H, lm, H, d_logits_last, c.vocab, B, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s));
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a13: greedy decode
+// ------------------------------------------------------------------------------------------------
+extern "C" int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, const int* h_next_pos, const int* h_ctx_len,
+                                   vz_stream stream) {
+    NEED_READY();
+    const vz_config& c = e->c;
+    hipStream_t s = (hipStream_t)stream;
+    VZ_CHECK_ARG(B >= 1 && B <= c.max_batch && B <= 4 && d_first_ids && h_next_pos && h_ctx_len, "decode_begin: B=%d unsupported (1..min(4,max_batch))", B);
+    const int mb = c.max_batch;
+    std::vector<int> h(3 * mb + 4, 0);
+    for (int b = 0; b < B; ++b) {
+        VZ_CHECK_ARG(h_ctx_len[b] >= 1 && h_ctx_len[b] < c.max_ctx, "decode_begin: ctx_len[%d]=%d outside [1,%d)", b, h_ctx_len[b], c.max_ctx);
+        h[b] = h_next_pos[b];            // pos
+        h[mb + b] = h_ctx_len[b];        // slot the next token is written to
+        h[2 * mb + b] = h_ctx_len[b] + 1;  // keys visible to the next token
+    }
+    RC(upload_ints(e, h.data(), h.size(), e->d_state + mb, s));   // [pos | slot | len | step=0]
+    VZ_CHECK_HIP(hipMemcpyAsync(e->d_state, d_first_ids, B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    e->dec_B = B;
+    return VZ_OK;
+}
+
+// one decode step, all launches on `s`; every quantity that changes between steps lives in device memory
+static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, float* d_logits_dbg, hipStream_t s) {
+    const vz_config& c = e->c;
+    const int B = e->dec_B, mb = c.max_batch;
+    const int H = c.hidden, D = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads, QKV = (Hq + 2 * Hkv) * D, I = c.inter;
+    int* cur = e->d_state; int* pos = cur + mb; int* slot = pos + mb; int* len = slot + mb; int* step = len + mb;
+    Carver m(e->arena, e->arena_bytes);
+    bf16_t* x = m.take<bf16_t>((size_t)B * H);
+    bf16_t* qkv = m.take<bf16_t>((size_t)B * QKV);
+    bf16_t* q = m.take<bf16_t>((size_t)B * H);
+    bf16_t* att = m.take<bf16_t>((size_t)B * H);
+    bf16_t* act = m.take<bf16_t>((size_t)B * I);
+    if (!m.ok) { vz_set_error("decode: workspace too small"); return VZ_ERR_STATE; }
+    int rc = VZ_OK;
+    { ProfScope ps(e, K_OTHER, s); RC(vz_launch_embed_tokens(cur, B, H, WB("llm.embed", (long)c.vocab * H), x, s)); }
+    for (int i = 0; i < c.n_layers; ++i) {
+        const std::string p = "llm." + std::to_string(i) + ".";
+        RC(linear(e, 0, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps));
+        { ProfScope ps(e, K_OTHER, s); RC(vz_launch_rope_kv(qkv, QKV, q, kc_of(e, i), vc_of(e, i), e->cosT, e->sinT, pos, slot, B, 1, Hq, Hkv, D, c.max_ctx, s)); }
+        {
+            ProfScope ps(e, K_ATTN_DEC, s);
+            AttnDecodeArgs a;
+            a.q = q; a.kc = kc_of(e, i); a.vc = vc_of(e, i); a.o = att; a.part = e->d_part;
+            a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_ctx = c.max_ctx; a.nsplit = e->nsplit; a.window = c.sliding_window;
+            a.scale = 0.08838834764831845f; a.ctx_len = len;
+            RC(vz_launch_attn_decode(a, s));
+        }
+        RC(linear(e, 0, att, H, WB(p + "o.w", (long)H * H), H, x, H, B, H, H, nullptr, x, H, VZ_ACT_NONE, 0, s));
+        RC(linear(e, 0, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps));
+        RC(linear(e, 0, act, I, WB(p + "down.w", (long)I * H), I, x, H, B, H, I, nullptr, x, H, VZ_ACT_NONE, 0, s));
+        if (rc) return rc;
+    }
+    RC(linear(e, 0, x, H, WB("llm.lm_head", (long)c.vocab * H), H, e->d_logits, c.vocab, B, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, WF("llm.norm", H), c.rms_eps));
+    if (rc) return rc;
+    if (d_logits_dbg) {
+        // debug copy is indexed by the host (eager mode only)
+        VZ_CHECK_HIP(hipMemcpyAsync(d_logits_dbg, e->d_logits, (size_t)B * c.vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    {
+        ProfScope ps(e, K_OTHER, s);
+        RC(vz_launch_argmax(e->d_logits, B, c.vocab, cur, pos, slot, len, d_out_ids, out_stride, step, s));
+        RC(vz_launch_step_advance(step, s));
+    }
+    return VZ_OK;
+}
+
+extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d_logits_dbg, vz_stream stream) {
+    NEED_READY();
+    const vz_config& c = e->c;
+    hipStream_t s = (hipStream_t)stream;
+    VZ_CHECK_ARG(e->dec_B >= 1, "decode_steps: call vz_llm_decode_begin first");
+    VZ_CHECK_ARG(n >= 1 && d_out_ids, "decode_steps: bad argument");
+    const int B = e->dec_B;
+    const size_t need = ((size_t)B * (3 * c.hidden + (c.n_heads + 2 * c.n_kv_heads) * c.head_dim + c.inter)) * 2 + 8192;
+    RC(ensure_arena(e, need));
+    const bool use_graph = !e->prof_on && !d_logits_dbg && getenv("VZ_NO_GRAPH") == nullptr;
+    int* step = e->d_state + 4 * c.max_batch;
+    VZ_CHECK_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
+    if (!use_graph) {
+        for (int i = 0; i < n; ++i)
+            RC(decode_step_launch(e, d_out_ids, n, d_logits_dbg ? d_logits_dbg + (size_t)i * B * c.vocab : nullptr, s));
+        return VZ_OK;
+    }
+    // Output pointer / stride and the workspace are kernel arguments frozen in the graph: re-capture when they change.
+    if (!e->dec_graph || e->dec_graph_B != B || e->dec_graph_n != n || e->dec_graph_out != d_out_ids || e->dec_graph_arena != e->arena) {
+        if (e->dec_graph) { hipGraphExecDestroy(e->dec_graph); e->dec_graph = nullptr; }
+        hipGraph_t graph;
+        if (!e->cap_stream) VZ_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+        VZ_CHECK_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+        int r = decode_step_launch(e, d_out_ids, n, nullptr, e->cap_stream);
+        hipError_t er = hipStreamEndCapture(e->cap_stream, &graph);
+        if (r) return r;
+        VZ_CHECK_HIP(er);
+        VZ_CHECK_HIP(hipGraphInstantiate(&e->dec_graph, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena;
+    }
+    for (int i = 0; i < n; ++i) VZ_CHECK_HIP(hipGraphLaunch(e->dec_graph, s));
+    return VZ_OK;
+}
+
+extern "C" int vz_prof_enable(vz_engine* e, int enable, int klass) {
+    VZ_CHECK_ARG(e, "prof: null engine");
+    e->prof_on = enable; e->prof_class = klass; e->prof_used = 0;
+    return VZ_OK;
+}
+extern "C" int vz_prof_read(vz_engine* e, long* n_launches, double* total_ms) {
+    VZ_CHECK_ARG(e && n_launches && total_ms, "prof: null argument");
+    double tot = 0;
+    for (size_t i = 0; i < e->prof_used; ++i) {
+        VZ_CHECK_HIP(hipEventSynchronize(e->prof_ev[i].second));
+        float ms = 0;
+        VZ_CHECK_HIP(hipEventElapsedTime(&ms, e->prof_ev[i].first, e->prof_ev[i].second));
+        tot += ms;
+    }
+    *n_launches = (long)e->prof_used; *total_ms = tot;
+    e->prof_used = 0;
+    return VZ_OK;
+}

@@ -318,6 +318,18 @@ int check_common(const LinearArgs& a) {
 
 }  // namespace
 
+int vz_init_gemm_kernels() {
+    static bool done = false;
+    if (done) return VZ_OK;
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    done = true;
+    return VZ_OK;
+}
+
 int vz_launch_gemm(const LinearArgs& a, hipStream_t s) {
     int rc = check_common(a);
     if (rc) return rc;
@@ -328,11 +340,7 @@ int vz_launch_gemm(const LinearArgs& a, hipStream_t s) {
     p.act = a.act; p.out_fp32 = a.out_fp32;
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-        attr_set = true;
-    }
+    { int r = vz_init_gemm_kernels(); if (r) return r; }
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), GEMM_LDS, s, p);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
@@ -357,16 +365,9 @@ int vz_launch_gemv(const LinearArgs& a, hipStream_t s) {
     if (blocks > 2048) blocks = 2048;
     const int mb = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
     const size_t lds = (size_t)mb * a.K * 2 + 64;
-#define VZ_GEMV_CASE(MB)                                                                                          \
-    case MB: {                                                                                                    \
-        static size_t max_lds_##MB = 0;                                                                           \
-        if (lds > max_lds_##MB) {                                                                                 \
-            VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<MB>,                                   \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));             \
-            max_lds_##MB = 64 * 1024;                                                                             \
-        }                                                                                                         \
-        hipLaunchKernelGGL(gemv_bf16_kernel<MB>, dim3(blocks), dim3(256), lds, s, p);                             \
-    } break;
+    { int r = vz_init_gemm_kernels(); if (r) return r; }
+#define VZ_GEMV_CASE(MB) \
+    case MB: hipLaunchKernelGGL(gemv_bf16_kernel<MB>, dim3(blocks), dim3(256), lds, s, p); break;
     switch (mb) {
         VZ_GEMV_CASE(1)
         VZ_GEMV_CASE(2)

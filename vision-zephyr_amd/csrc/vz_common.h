@@ -124,8 +124,11 @@ int vz_launch_clip_assemble(const bf16_t* patch_out, const bf16_t* cls, const bf
                             bf16_t* out, hipStream_t s);
 int vz_launch_fusion(const bf16_t* hs_base, long layer_stride, int first_layer, int groups, int per_group, int T,
                      int tokens, int C, bf16_t* out, hipStream_t s);
-int vz_launch_argmax(const float* logits, int rows, int cols, int* ids, int* pos, int* ctx, int* out_ids,
+int vz_launch_argmax(const float* logits, int rows, int cols, int* ids, int* pos, int* slot, int* len, int* out_ids,
                      int out_stride, const int* step, hipStream_t s);
+// set dynamic-LDS limits of every kernel up front (never inside a stream capture)
+int vz_init_gemm_kernels();
+int vz_init_attention_kernels();
 int vz_launch_copy_rows(const bf16_t* src, long src_stride, bf16_t* dst, long dst_stride, int rows, int cols,
                         hipStream_t s);
 int vz_launch_step_advance(int* step, hipStream_t s);

@@ -1,0 +1,333 @@
+"""VisZephyrForCausalLM for MI355X: the reference's model API
+(ref:vis_zephyr/model/language_model/vis_zephyr.py:19-174) on top of the native engine.
+
+The reference class IS an HF `MistralForCausalLM` and delegates generation to `GenerationMixin`.
+This one owns a `vz_hip.Engine` (weights + KV cache in HBM, hand-written HIP kernels) and implements
+`forward` / `generate` itself with the same observable contract:
+
+  * forward(input_ids|inputs_embeds, images=...) -> object with .loss/.logits/.past_key_values;
+    logits for ALL positions, fp32, [B,S,vocab] (what the reference's forward returns).
+  * generate(input_ids, images=..., images_size=..., do_sample, temperature, top_p, max_new_tokens,
+    eos_token_id, pad_token_id, streamer, stopping_criteria, use_cache) -> LongTensor [B, n_new]
+    holding NEW tokens only (HF semantics when generation starts from inputs_embeds; Appendix A Q6).
+    streamer.put()/end() and stopping_criteria(ids, scores) are invoked once per token, as HF does.
+  * `inputs_embeds=` passed to generate raises NotImplementedError (ref :113-114).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional, Sequence, Union
+
+import torch
+
+from vz_hip.engine import Engine
+from vz_hip.synth import ArchConfig
+
+from ..vis_zephyr_arch import VisZephyrMetaForCausalLM, VisZephyrMetaModel
+
+try:                                    # configuration class only - no HF modelling code on this path
+    from transformers import MistralConfig as _BaseConfig
+except Exception:                       # pragma: no cover - transformers absent
+    class _BaseConfig:                  # minimal stand-in with attribute storage
+        def __init__(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+
+class VisZephyrConfig(_BaseConfig):
+    model_type = "vis_zephyr"
+
+
+def arch_from_config(config) -> ArchConfig:
+    g = lambda k, d: getattr(config, k, d) if getattr(config, k, d) is not None else d  # noqa: E731
+    hidden = g("hidden_size", 4096)
+    heads = g("num_attention_heads", 32)
+    return ArchConfig(hidden=hidden, inter=g("intermediate_size", 14336), n_layers=g("num_hidden_layers", 32),
+                      n_heads=heads, n_kv_heads=g("num_key_value_heads", 8), head_dim=g("head_dim", hidden // heads),
+                      vocab=g("vocab_size", 32000), rms_eps=g("rms_norm_eps", 1e-5),
+                      rope_theta=float(g("rope_theta", 10000.0)), sliding_window=g("sliding_window", 4096))
+
+
+class _Embedding:
+    """`model.get_model().embed_tokens(ids)` (ref vis_zephyr_arch.py:170,211,248,275)."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def __call__(self, ids):
+        return self._owner.engine.embed_tokens(ids)
+
+    @property
+    def weight(self):
+        return self._owner.engine.w["llm.embed"]
+
+
+class _LMHead:
+    def __init__(self, owner):
+        self._owner = owner
+
+    @property
+    def weight(self):
+        return self._owner.engine.w["llm.lm_head"]
+
+    def __call__(self, hidden):
+        from vz_hip import binding as B
+        h = hidden.to(self._owner.device, torch.bfloat16)
+        return B.linear(h.reshape(-1, h.shape[-1]).contiguous(), self.weight, out_fp32=True).view(*h.shape[:-1], -1)
+
+
+class VisZephyrModel(VisZephyrMetaModel):
+    """`model.get_model()`: embed_tokens + vision tower + projector (ref vis_zephyr.py:22-26)."""
+    config_class = VisZephyrConfig
+
+    def __init__(self, config, owner):
+        self.config = config
+        self.embed_tokens = _Embedding(owner)
+        self._init_vision(config, owner)
+
+
+class PastKeyValues:
+    """The KV cache lives in the engine ([layer][k|v][slot][kv_head][pos][128] bf16); this handle records how
+    many positions of each slot are filled."""
+
+    def __init__(self, lengths: Sequence[int]):
+        self.lengths = list(lengths)
+
+    def get_seq_length(self, layer_idx: int = 0):
+        return max(self.lengths) if self.lengths else 0
+
+
+class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
+    config_class = VisZephyrConfig
+
+    def __init__(self, config, device: Union[str, torch.device] = "cuda:0", max_batch: int = 1,
+                 max_ctx: int = 4096, max_tiles: int = 8, max_text: int = 2048, engine: Optional[Engine] = None):
+        self.config = config
+        self.arch = arch_from_config(config)
+        self.engine = engine if engine is not None else Engine(self.arch, device=device, max_batch=max_batch,
+                                                               max_ctx=max_ctx, max_tiles=max_tiles,
+                                                               max_text=max_text)
+        self.device = self.engine.device
+        self.dtype = torch.bfloat16
+        self.model = VisZephyrModel(config, self)
+        self.lm_head = _LMHead(self)
+        self.generation_config = SimpleNamespace(eos_token_id=getattr(config, "eos_token_id", 2),
+                                                 pad_token_id=getattr(config, "pad_token_id", None))
+
+    # ---- construction helpers -------------------------------------------------------------------
+    @classmethod
+    def from_synthetic(cls, config, seed: int = 0, **kw):
+        m = cls(config, **kw)
+        m.engine.load_synthetic(seed)
+        if m.get_vision_tower() is not None:
+            m.get_vision_tower().is_loaded = True
+        return m
+
+    def load_state_dict_stream(self, named_tensors):
+        """feed (reference key, tensor) pairs - e.g. safetensors shards + mm_projector.bin
+        (ref:vis_zephyr/model/builder.py:102-138)."""
+        self.engine.load_weights(named_tensors)
+
+    # nn.Module-flavoured no-ops the reference's callers invoke
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def half(self):
+        return self
+
+    def get_model(self):
+        return self.model
+
+    def resize_token_embeddings(self, n: int):
+        """ref:vis_zephyr/model/builder.py:141-153 grows embed_tokens / lm_head by `<im_patch>`; new rows are
+        the mean of the old ones (HF mean-resizing)."""
+        old = self.arch.vocab
+        if n == old:
+            return self.model.embed_tokens
+        raise NotImplementedError("resize_token_embeddings: build the engine with config.vocab_size = len(tokenizer) "
+                                  "and load the resized tables (vz_hip.weights.resize_vocab)")
+
+    # ---- forward (a2) -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, images=None, images_size=None, return_dict=None, **kwargs):
+        if past_key_values is not None:
+            raise NotImplementedError("forward() with an external past_key_values: use generate(); the cache is "
+                                      "engine-owned")
+        if inputs_embeds is None:
+            (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels) = \
+                self.prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
+                                                          labels, images, images_size)
+        if inputs_embeds is None:
+            inputs_embeds = self.get_model().embed_tokens(input_ids)
+        Bsz, S = inputs_embeds.shape[0], inputs_embeds.shape[1]
+        seqlens = self._seqlens(attention_mask, Bsz, S)
+        logits, _ = self.engine.prefill(inputs_embeds, seqlens, position_ids, all_logits=True, last_logits=False)
+        loss = None
+        if labels is not None:
+            lab = labels.to(logits.device)
+            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(),
+                                                     lab[:, 1:].reshape(-1), ignore_index=-100)
+        return SimpleNamespace(loss=loss, logits=logits, past_key_values=PastKeyValues(seqlens), hidden_states=None,
+                               attentions=None)
+
+    __call__ = forward
+
+    @staticmethod
+    def _seqlens(attention_mask, Bsz, S) -> List[int]:
+        if attention_mask is None:
+            return [S] * Bsz
+        m = attention_mask.bool().cpu()
+        lens = m.sum(1).tolist()
+        for b in range(Bsz):
+            if not bool(m[b, :lens[b]].all()):
+                raise NotImplementedError("only right-padded (prefix) attention masks are built in the MI355X engine")
+        return [max(1, int(x)) for x in lens]
+
+    # ---- generate (a3, a13) -------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids: Optional[torch.Tensor] = None, images=None, images_size=None, **kwargs):
+        position_ids = kwargs.pop("position_ids", None)
+        attention_mask = kwargs.pop("attention_mask", None)
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported in this generate function.")
+        if images is not None:
+            (_, position_ids, attention_mask, _, inputs_embeds, _) = self.prepare_inputs_labels_for_multimodal(
+                input_ids, position_ids, attention_mask, None, None, images, images_size)
+            if inputs_embeds is None:       # single-token prompt: the reference's early-out returns the ids untouched
+                inputs_embeds = self.get_model().embed_tokens(input_ids)
+        else:
+            inputs_embeds = self.get_model().embed_tokens(input_ids)
+        return self._generate_from_embeds(inputs_embeds, attention_mask, position_ids, **kwargs)
+
+    def _generate_from_embeds(self, inputs_embeds, attention_mask, position_ids, max_new_tokens: Optional[int] = None,
+                              max_length: Optional[int] = None, do_sample: bool = False, temperature: float = 1.0,
+                              top_p: Optional[float] = None, top_k: Optional[int] = None, eos_token_id=None,
+                              pad_token_id=None, streamer=None, stopping_criteria=None, use_cache: bool = True,
+                              num_beams: int = 1, generator: Optional[torch.Generator] = None,
+                              sync_every: int = 16, **unused):
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not on the reference's inference path (cli/eval use sampling/greedy)")
+        Bsz, S = inputs_embeds.shape[0], inputs_embeds.shape[1]
+        if max_new_tokens is None:
+            max_new_tokens = 20 if max_length is None else max(1, max_length - S)
+        if eos_token_id is None:
+            eos_token_id = self.generation_config.eos_token_id
+        eos = set([eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id or []))
+        if pad_token_id is None:
+            pad_token_id = self.generation_config.pad_token_id
+        if pad_token_id is None:
+            pad_token_id = min(eos) if eos else 0
+        greedy = (not do_sample) or temperature is None or temperature <= 0
+        seqlens = self._seqlens(attention_mask, Bsz, S)
+        outs = []
+        for b in range(Bsz):               # the reference's inference callers are batch 1 (eval_vqa.py:119-120)
+            outs.append(self._generate_one(inputs_embeds[b:b + 1, :seqlens[b]],
+                                           None if position_ids is None else position_ids[b:b + 1, :seqlens[b]],
+                                           max_new_tokens, greedy, temperature, top_p, top_k, eos, streamer if Bsz == 1 else None,
+                                           stopping_criteria, generator, sync_every))
+        n = max(len(o) for o in outs)
+        res = torch.full((Bsz, n), pad_token_id, dtype=torch.long, device=self.device)
+        for b, o in enumerate(outs):
+            res[b, :len(o)] = torch.tensor(o, dtype=torch.long, device=self.device)
+        return res
+
+    def _generate_one(self, embeds, position_ids, max_new, greedy, temperature, top_p, top_k, eos, streamer,
+                      stopping_criteria, generator, sync_every) -> List[int]:
+        eng = self.engine
+        S = embeds.shape[1]
+        if S + max_new > eng.max_ctx:
+            raise ValueError(f"prompt ({S}) + max_new_tokens ({max_new}) exceeds the engine's max_ctx ({eng.max_ctx})")
+        _, last = eng.prefill(embeds, [S], position_ids, all_logits=False, last_logits=True)
+        next_pos = S if position_ids is None else int(position_ids[0, -1]) + 1
+        per_token = streamer is not None or stopping_criteria is not None or not greedy
+        out: List[int] = []
+
+        def pick(logits_row: torch.Tensor) -> int:
+            if greedy:
+                from vz_hip import binding as B
+                return int(B.argmax(logits_row.view(1, -1).contiguous())[0])
+            return _sample(logits_row, temperature, top_p, top_k, generator)
+
+        if streamer is not None:
+            # HF hands the (empty, since generation starts from embeddings) prompt ids to the streamer first;
+            # TextStreamer(skip_prompt=True) swallows exactly one put() as "the prompt"
+            streamer.put(torch.empty((1, 0), dtype=torch.long))
+        tok = pick(last[0])
+        out.append(tok)
+        if self._emit(out, streamer, stopping_criteria, last, eos):
+            return self._finish(out, streamer)
+        if per_token:
+            while len(out) < max_new:
+                eng.decode_begin(torch.tensor([out[-1]], dtype=torch.int32), [next_pos + len(out) - 1], [S + len(out) - 1])
+                ids, lg = eng.decode_steps(1, return_logits=True)
+                tok = int(ids[0, 0]) if greedy else pick(lg[0, 0])
+                out.append(tok)
+                if self._emit(out, streamer, stopping_criteria, lg[0], eos):
+                    break
+            return self._finish(out, streamer)
+        # greedy without host callbacks: steps are enqueued back to back, the host looks at the ids every
+        # `sync_every` tokens only to honour eos
+        eng.decode_begin(torch.tensor([tok], dtype=torch.int32), [next_pos], [S])
+        remaining = max_new - 1
+        while remaining > 0:
+            n = min(sync_every, remaining) if eos else remaining
+            ids = eng.decode_steps(n)[0].tolist()
+            remaining -= n
+            for t in ids:
+                out.append(int(t))
+                if int(t) in eos:
+                    return out
+        return out
+
+    def _emit(self, out, streamer, stopping_criteria, scores, eos) -> bool:
+        """per-token host callbacks; returns True when generation must stop."""
+        if streamer is not None:
+            streamer.put(torch.tensor([out[-1]], dtype=torch.long))
+        stop = out[-1] in eos
+        if stopping_criteria is not None and not stop:
+            ids = torch.tensor([out], dtype=torch.long, device=self.device)
+            crits = stopping_criteria if isinstance(stopping_criteria, (list, tuple)) else [stopping_criteria]
+            for c in crits:
+                r = c(ids, scores)
+                if bool(r.all() if torch.is_tensor(r) else r):
+                    stop = True
+        return stop
+
+    @staticmethod
+    def _finish(out, streamer):
+        if streamer is not None:
+            streamer.end()
+        return out
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, inputs_embeds=None, **kwargs):
+        """ref vis_zephyr.py:144-170: pass-through that re-attaches images / images_size."""
+        images = kwargs.pop("images", None)
+        images_size = kwargs.pop("images_size", None)
+        inputs = dict(input_ids=input_ids, past_key_values=past_key_values, inputs_embeds=inputs_embeds, **kwargs)
+        if images is not None:
+            inputs["images"] = images
+        if images_size is not None:
+            inputs["images_size"] = images_size
+        return inputs
+
+
+def _sample(logits_row, temperature, top_p, top_k, generator) -> int:
+    """temperature / top-k / top-p sampling on the fp32 logits (hf:generation/utils.py _sample + logits warpers).
+    Host-side control flow of the slow path; the per-token logits come from the engine."""
+    x = logits_row.float() / float(temperature)
+    if top_k is not None and top_k > 0:
+        kth = torch.topk(x, min(top_k, x.numel())).values[-1]
+        x = torch.where(x < kth, torch.full_like(x, float("-inf")), x)
+    if top_p is not None and top_p < 1.0:
+        sx, si = torch.sort(x, descending=False)
+        cp = torch.softmax(sx, dim=-1).cumsum(-1)
+        remove = cp <= (1 - top_p)
+        remove[-1] = False
+        x = x.masked_fill(torch.zeros_like(remove).scatter(0, si, remove), float("-inf"))
+    p = torch.softmax(x, dim=-1)
+    return int(torch.multinomial(p, 1, generator=generator))

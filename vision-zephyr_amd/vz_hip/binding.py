@@ -1,0 +1,209 @@
+"""ctypes binding of libviszephyr_hip.so (include/viszephyr.h).
+
+The product path has no CPU fallback: if the shared library is missing, or a call fails, this
+module raises.  torch is used only for device memory and streams (tensor.data_ptr(),
+torch.cuda.current_stream()).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libviszephyr_hip.so")
+
+VZ_OK, VZ_ERR_ARG, VZ_ERR_HIP, VZ_ERR_STATE, VZ_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
+K_GEMM, K_GEMV, K_ATTN, K_ATTN_DEC, K_NORM, K_OTHER = range(6)
+
+
+class VzConfig(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int), ("inter", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int),
+        ("n_kv_heads", C.c_int), ("head_dim", C.c_int), ("vocab", C.c_int),
+        ("rms_eps", C.c_float), ("rope_theta", C.c_float), ("sliding_window", C.c_int),
+        ("clip_hidden", C.c_int), ("clip_inter", C.c_int), ("clip_layers", C.c_int), ("clip_heads", C.c_int),
+        ("clip_image", C.c_int), ("clip_patch", C.c_int), ("clip_eps", C.c_float),
+        ("qf_queries", C.c_int), ("qf_blocks", C.c_int), ("qf_heads", C.c_int), ("qf_kv_dim", C.c_int),
+        ("qf_eps", C.c_float),
+        ("fusion_groups", C.c_int), ("fusion_layers_per_group", C.c_int),
+        ("max_batch", C.c_int), ("max_ctx", C.c_int), ("max_tiles", C.c_int), ("max_text", C.c_int),
+        ("tp_size", C.c_int), ("tp_rank", C.c_int),
+    ]
+
+
+# every symbol include/viszephyr.h declares: (restype, argtypes)
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+SYMBOLS = {
+    "vz_last_error": (C.c_char_p, []),
+    "vz_abi_version": (_I, []),
+    "vz_target_arch": (C.c_char_p, []),
+    "vz_op_linear": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "vz_op_linear_impl": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "vz_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _P]),
+    "vz_op_rmsnorm": (_I, [_P, _I, _P, _I, _P, _I, _I, _F, _P]),
+    "vz_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I] + [_L] * 12 + [_F, _I, _I, _I, _P, _P]),
+    "vz_op_argmax": (_I, [_P, _I, _I, _P, _P]),
+    "vz_op_rope_kv": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vz_op_attention_decode": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "vz_engine_create": (_I, [C.POINTER(VzConfig), C.POINTER(_P)]),
+    "vz_engine_destroy": (_I, [_P]),
+    "vz_engine_set_weight": (_I, [_P, C.c_char_p, _P, _I, _L]),
+    "vz_engine_finalize": (_I, [_P]),
+    "vz_engine_set_rope": (_I, [_P, _P, _P, _I]),
+    "vz_clip_fused_features": (_I, [_P, _P, _I, _P, _P, _P]),
+    "vz_qformer": (_I, [_P, _P, _I, _P, _I, _I, C.POINTER(C.c_int), _P, _P]),
+    "vz_embed_splice": (_I, [_P, _P, _P, _I, _P, _P, _P]),
+    "vz_llm_prefill": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int), _P, _P, _P, _P]),
+    "vz_llm_decode_begin": (_I, [_P, _I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
+    "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
+    "vz_prof_enable": (_I, [_P, _I, _I]),
+    "vz_prof_read": (_I, [_P, C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the HIP library and type every entry point.  Raises if it is missing: there is no
+    eager/CPU fallback for the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `make -C vision-zephyr_amd/csrc` (or __graft_entry__.build()). "
+            "The Vision-Zephyr MI355X path has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def lib() -> C.CDLL:
+    return load_library()
+
+
+class VzError(RuntimeError):
+    pass
+
+
+def check(rc: int):
+    if rc == VZ_OK:
+        return
+    msg = lib().vz_last_error().decode(errors="replace")
+    if rc == VZ_ERR_ARG:
+        raise ValueError(msg)
+    if rc == VZ_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise VzError(f"libviszephyr_hip error {rc}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("libviszephyr_hip operates on device tensors only (no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------
+# operator wrappers (used by tests and by nothing else in the product: the engine calls the same
+# launchers natively)
+# ------------------------------------------------------------------------------------------------
+def linear(x: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: int = ACT_NONE, out_fp32=False,
+           impl: Optional[int] = None) -> torch.Tensor:
+    """epi(x[M,K] @ w[N,K]^T); bf16 in, bf16 (or fp32) out."""
+    _need_cuda(x, w, bias, residual)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2
+    assert x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    out = torch.empty(M, n_out, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=x.device)
+    if bias is not None:
+        assert bias.dtype == torch.float32
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.stride(1) == 1
+    args = (ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias), ptr(residual),
+            0 if residual is None else residual.stride(0), act, int(out_fp32), stream_ptr(x.device))
+    if impl is None:
+        check(lib().vz_op_linear(*args))
+    else:
+        check(lib().vz_op_linear_impl(impl, *args))
+    return out
+
+
+def layernorm(x, w, b, eps):
+    _need_cuda(x, w, b)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    y = torch.empty_like(x)
+    check(lib().vz_op_layernorm(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(w), ptr(b), x.shape[0], x.shape[1],
+                                eps, stream_ptr(x.device)))
+    return y
+
+
+def rmsnorm(x, w, eps):
+    _need_cuda(x, w)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    y = torch.empty_like(x)
+    check(lib().vz_op_rmsnorm(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(w), x.shape[0], x.shape[1], eps,
+                              stream_ptr(x.device)))
+    return y
+
+
+def attention(q, k, v, scale, causal=False, q_pos0=0, window=0, kv_len=None):
+    """q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (any strides with unit stride on D) -> [B,Sq,Hq,D]."""
+    _need_cuda(q, k, v, kv_len)
+    B, Sq, Hq, D = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    for t in (q, k, v):
+        assert t.dtype == torch.bfloat16 and t.stride(3) == 1
+    o = torch.empty(B, Sq, Hq, D, dtype=torch.bfloat16, device=q.device)
+    if kv_len is not None:
+        assert kv_len.dtype == torch.int32
+    check(lib().vz_op_attention(ptr(q), ptr(k), ptr(v), ptr(o), B, Sq, Sk, Hq, Hkv, D,
+                                q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                                v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2),
+                                float(scale), int(causal), q_pos0, window, ptr(kv_len), stream_ptr(q.device)))
+    return o
+
+
+def argmax(logits):
+    _need_cuda(logits)
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.is_contiguous()
+    ids = torch.empty(logits.shape[0], dtype=torch.int32, device=logits.device)
+    check(lib().vz_op_argmax(ptr(logits), logits.shape[0], logits.shape[1], ptr(ids), stream_ptr(logits.device)))
+    return ids
+
+
+def rope_kv(qkv, cos, sin, pos, slot, kcache, vcache, B_, S, Hq, Hkv, D):
+    """qkv bf16 [B*S,(Hq+2Hkv)*D]; returns rotated q [B*S,Hq,D]; K/V written into the caches in place."""
+    _need_cuda(qkv, cos, sin, pos, slot, kcache, vcache)
+    q = torch.empty(B_ * S, Hq, D, dtype=torch.bfloat16, device=qkv.device)
+    check(lib().vz_op_rope_kv(ptr(qkv), qkv.stride(0), ptr(q), ptr(kcache), ptr(vcache), ptr(cos), ptr(sin), ptr(pos),
+                              ptr(slot), B_, S, Hq, Hkv, D, kcache.shape[2], stream_ptr(qkv.device)))
+    return q
+
+
+def attention_decode(q, kcache, vcache, ctx_len, scale, nsplit=8, window=0):
+    """q bf16 [B,Hq,D]; caches [B,Hkv,max_ctx,D]; ctx_len int32 [B] -> [B,Hq,D]."""
+    _need_cuda(q, kcache, vcache, ctx_len)
+    Bn, Hq, D = q.shape
+    ws = torch.empty(Bn * Hq * nsplit * (D + 2), dtype=torch.float32, device=q.device)
+    o = torch.empty_like(q)
+    check(lib().vz_op_attention_decode(ptr(q), ptr(kcache), ptr(vcache), ptr(o), ptr(ws), Bn, Hq, kcache.shape[1], D,
+                                       kcache.shape[2], nsplit, window, float(scale), ptr(ctx_len), stream_ptr(q.device)))
+    return o

@@ -1,0 +1,352 @@
+"""Python owner of one native engine (vz_engine): weight packing from the reference's state-dict
+names into the engine's HBM layout, and thin stage calls.  torch is plumbing only (device memory,
+dtype casts at load time, streams); every stage runs in libviszephyr_hip.so.
+
+HBM layout: all matrices bf16 row-major [out_features, in_features] exactly
+as the reference stores them, except
+  * q/k/v (CLIP, Zephyr) stacked into one [3C,C] / [6144,4096] matrix -> one GEMM per layer,
+  * cross-attention k|v stacked [8192,5120],
+  * Zephyr gate/up interleaved in 16-row groups [16 gate | 16 up | ...] so the SwiGLU product is
+    formed inside the GEMM epilogue,
+  * the CLIP patch convolution flattened to [1024, 588] and zero-padded to K = 640.
+Vectors (biases, LayerNorm/RMSNorm scales) are fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import binding as B
+from .synth import ArchConfig, iter_state_dict
+
+_CLIP_PREFIXES = ("model.vision_tower.vision_tower.vision_model.", "model.vision_tower.vision_tower.")
+_QF = "model.mm_projector."
+
+
+def rope_tables(cfg: ArchConfig, max_pos: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp32 cos/sin [max_pos, head_dim/2] (hf:models/mistral/modeling_mistral.py:262-317: inv_freq =
+    theta^(-2i/d), angle = pos * inv_freq computed in fp32)."""
+    d = cfg.head_dim
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
+    fr = torch.arange(max_pos, dtype=torch.float32).unsqueeze(-1) * inv
+    return fr.cos().contiguous(), fr.sin().contiguous()
+
+
+class Engine:
+    def __init__(self, cfg: ArchConfig, device="cuda:0", max_batch: int = 1, max_ctx: int = 4096,
+                 max_tiles: int = 8, max_text: int = 2048):
+        self.lib = B.load_library()            # raises when the HIP library is absent: no fallback
+        if not torch.cuda.is_available():
+            raise RuntimeError("vz_hip.Engine needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.max_batch, self.max_ctx, self.max_tiles, self.max_text = max_batch, max_ctx, max_tiles, max_text
+        c = B.VzConfig(
+            hidden=cfg.hidden, inter=cfg.inter, n_layers=cfg.n_layers, n_heads=cfg.n_heads, n_kv_heads=cfg.n_kv_heads,
+            head_dim=cfg.head_dim, vocab=cfg.vocab, rms_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+            sliding_window=cfg.sliding_window, clip_hidden=cfg.clip_hidden, clip_inter=cfg.clip_inter,
+            clip_layers=cfg.clip_layers, clip_heads=cfg.clip_heads, clip_image=cfg.clip_image,
+            clip_patch=cfg.clip_patch, clip_eps=cfg.clip_eps, qf_queries=cfg.qf_queries, qf_blocks=cfg.qf_blocks,
+            qf_heads=cfg.qf_heads, qf_kv_dim=cfg.qf_kv_dim, qf_eps=cfg.qf_eps, fusion_groups=cfg.fusion_groups,
+            fusion_layers_per_group=cfg.fusion_layers_per_group, max_batch=max_batch, max_ctx=max_ctx,
+            max_tiles=max_tiles, max_text=max_text, tp_size=1, tp_rank=0)
+        h = C.c_void_p()
+        B.check(self.lib.vz_engine_create(C.byref(c), C.byref(h)))
+        self.h = h
+        self.w: Dict[str, torch.Tensor] = {}
+        self._registered = set()
+        cos, sin = rope_tables(cfg, max_ctx)
+        self._cos, self._sin = cos.to(self.device), sin.to(self.device)
+        B.check(self.lib.vz_engine_set_rope(self.h, B.ptr(self._cos), B.ptr(self._sin), max_ctx))
+        self.ready = False
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.vz_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --------------------------------------------------------------------------------------------
+    # weights
+    # --------------------------------------------------------------------------------------------
+    def _dest(self, name: str, shape, dtype) -> torch.Tensor:
+        t = self.w.get(name)
+        if t is None:
+            t = torch.zeros(*shape, dtype=dtype, device=self.device)
+            self.w[name] = t
+        return t
+
+    def _mat(self, name, shape, src: torch.Tensor, rows: Optional[slice] = None):
+        d = self._dest(name, shape, torch.bfloat16)
+        s = src.to(self.device, non_blocking=True).to(torch.bfloat16)
+        (d if rows is None else d[rows]).copy_(s.reshape((d if rows is None else d[rows]).shape))
+
+    def _vec(self, name, n, src: torch.Tensor, sl: Optional[slice] = None):
+        d = self._dest(name, (n,), torch.float32)
+        s = src.to(self.device, non_blocking=True).to(torch.float32)
+        (d if sl is None else d[sl]).copy_(s.reshape(-1))
+
+    def add_weight(self, name: str, t: torch.Tensor) -> bool:
+        """Consume one tensor under its reference state-dict key.  Returns False for keys that are
+        not on the hot path (CLIP post_layernorm, buffers)."""
+        cfg = self.cfg
+        H, Cc, I = cfg.hidden, cfg.clip_hidden, cfg.inter
+        for pre in _CLIP_PREFIXES:
+            if name.startswith(pre):
+                return self._add_clip(name[len(pre):], t)
+        if name.startswith(_QF):
+            return self._add_qformer(name[len(_QF):], t)
+        if name == "model.embed_tokens.weight":
+            self._mat("llm.embed", (cfg.vocab, H), t)
+        elif name == "lm_head.weight":
+            self._mat("llm.lm_head", (cfg.vocab, H), t)
+        elif name == "model.norm.weight":
+            self._vec("llm.norm", H, t)
+        else:
+            m = re.fullmatch(r"model\.layers\.(\d+)\.(.+)", name)
+            if not m:
+                return False
+            i, rest = int(m.group(1)), m.group(2)
+            p = f"llm.{i}."
+            qd, kvd = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
+            if rest == "input_layernorm.weight":
+                self._vec(p + "in_norm", H, t)
+            elif rest == "post_attention_layernorm.weight":
+                self._vec(p + "post_norm", H, t)
+            elif rest == "self_attn.q_proj.weight":
+                self._mat(p + "qkv.w", (qd + 2 * kvd, H), t, slice(0, qd))
+            elif rest == "self_attn.k_proj.weight":
+                self._mat(p + "qkv.w", (qd + 2 * kvd, H), t, slice(qd, qd + kvd))
+            elif rest == "self_attn.v_proj.weight":
+                self._mat(p + "qkv.w", (qd + 2 * kvd, H), t, slice(qd + kvd, qd + 2 * kvd))
+            elif rest == "self_attn.o_proj.weight":
+                self._mat(p + "o.w", (H, qd), t)
+            elif rest in ("mlp.gate_proj.weight", "mlp.up_proj.weight"):
+                d = self._dest(p + "gu.w", (2 * I, H), torch.bfloat16).view(I // 16, 2, 16, H)
+                d[:, 0 if "gate" in rest else 1].copy_(t.to(self.device).to(torch.bfloat16).view(I // 16, 16, H))
+            elif rest == "mlp.down_proj.weight":
+                self._mat(p + "down.w", (H, I), t)
+            else:
+                return False
+        return True
+
+    def _add_clip(self, k: str, t: torch.Tensor) -> bool:
+        cfg = self.cfg
+        Cc = cfg.clip_hidden
+        kreal = 3 * cfg.clip_patch * cfg.clip_patch
+        kpad = (kreal + 63) // 64 * 64
+        if k == "embeddings.class_embedding":
+            self._mat("clip.cls", (Cc,), t)
+        elif k == "embeddings.patch_embedding.weight":
+            d = self._dest("clip.patch_w", (Cc, kpad), torch.bfloat16)
+            d[:, :kreal].copy_(t.to(self.device).to(torch.bfloat16).reshape(Cc, kreal))
+        elif k == "embeddings.position_embedding.weight":
+            self._mat("clip.pos", (cfg.clip_tokens, Cc), t)
+        elif k.startswith("pre_layrnorm."):
+            self._vec("clip.pre_ln." + ("w" if k.endswith("weight") else "b"), Cc, t)
+        else:
+            m = re.fullmatch(r"encoder\.layers\.(\d+)\.(.+)\.(weight|bias)", k)
+            if not m:
+                return False
+            i, mod, wb = int(m.group(1)), m.group(2), m.group(3)
+            p = f"clip.{i}."
+            isw = wb == "weight"
+            if mod in ("layer_norm1", "layer_norm2"):
+                self._vec(p + ("ln1." if mod.endswith("1") else "ln2.") + ("w" if isw else "b"), Cc, t)
+            elif mod in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"):
+                j = "qkv".index(mod[-6])
+                sl = slice(j * Cc, (j + 1) * Cc)
+                if isw:
+                    self._mat(p + "qkv.w", (3 * Cc, Cc), t, sl)
+                else:
+                    self._vec(p + "qkv.b", 3 * Cc, t, sl)
+            elif mod == "self_attn.out_proj":
+                self._mat(p + "o.w", (Cc, Cc), t) if isw else self._vec(p + "o.b", Cc, t)
+            elif mod == "mlp.fc1":
+                self._mat(p + "fc1.w", (cfg.clip_inter, Cc), t) if isw else self._vec(p + "fc1.b", cfg.clip_inter, t)
+            elif mod == "mlp.fc2":
+                self._mat(p + "fc2.w", (Cc, cfg.clip_inter), t) if isw else self._vec(p + "fc2.b", Cc, t)
+            else:
+                return False
+        return True
+
+    def _add_qformer(self, k: str, t: torch.Tensor) -> bool:
+        cfg = self.cfg
+        H, KD = cfg.hidden, cfg.qf_kv_dim
+        if k == "learned_queries":
+            self._mat("qf.queries", (cfg.qf_queries, H), t)
+        elif k in ("pre_norm.weight", "pre_norm.bias"):
+            self._vec("qf.pre_norm." + ("w" if k.endswith("weight") else "b"), KD, t)
+        elif k in ("norm.weight", "norm.bias"):
+            self._vec("qf.norm." + ("w" if k.endswith("weight") else "b"), H, t)
+        else:
+            m = re.fullmatch(r"blocks\.(\d+)\.(.+)", k)
+            if not m:
+                return False
+            i, rest = int(m.group(1)), m.group(2)
+            p = f"qf.{i}."
+            mm = re.fullmatch(r"norm([123])\.(weight|bias)", rest)
+            if mm:
+                self._vec(p + f"n{mm.group(1)}." + ("w" if mm.group(2) == "weight" else "b"), H, t)
+            elif rest == "self_attn.in_proj_weight":
+                self._mat(p + "sa_in.w", (3 * H, H), t)
+            elif rest == "self_attn.in_proj_bias":
+                self._vec(p + "sa_in.b", 3 * H, t)
+            elif rest == "self_attn.out_proj.weight":
+                self._mat(p + "sa_out.w", (H, H), t)
+            elif rest == "self_attn.out_proj.bias":
+                self._vec(p + "sa_out.b", H, t)
+            elif rest == "cross_attn.q_proj_weight":
+                self._mat(p + "ca_q.w", (H, H), t)
+            elif rest == "cross_attn.k_proj_weight":
+                self._mat(p + "ca_kv.w", (2 * H, KD), t, slice(0, H))
+            elif rest == "cross_attn.v_proj_weight":
+                self._mat(p + "ca_kv.w", (2 * H, KD), t, slice(H, 2 * H))
+            elif rest == "cross_attn.in_proj_bias":
+                tt = t.reshape(-1)
+                self._vec(p + "ca_q.b", H, tt[:H])
+                self._vec(p + "ca_kv.b", 2 * H, tt[H:])
+            elif rest == "cross_attn.out_proj.weight":
+                self._mat(p + "ca_out.w", (H, H), t)
+            elif rest == "cross_attn.out_proj.bias":
+                self._vec(p + "ca_out.b", H, t)
+            elif rest == "ffn.0.weight":
+                self._mat(p + "ffn1.w", (2 * H, H), t)
+            elif rest == "ffn.0.bias":
+                self._vec(p + "ffn1.b", 2 * H, t)
+            elif rest == "ffn.2.weight":
+                self._mat(p + "ffn2.w", (H, 2 * H), t)
+            elif rest == "ffn.2.bias":
+                self._vec(p + "ffn2.b", H, t)
+            else:
+                return False
+        return True
+
+    def load_weights(self, named: Iterable[Tuple[str, torch.Tensor]]):
+        for name, t in named:
+            self.add_weight(name, t)
+        self.finalize()
+
+    def load_synthetic(self, seed: int = 0):
+        """hash-generated weights, produced on the device (bit-identical to the CPU generator)."""
+        self.load_weights(iter_state_dict(self.cfg, seed, device=self.device))
+
+    def finalize(self):
+        for name, t in self.w.items():
+            if name in self._registered:
+                continue
+            B.check(self.lib.vz_engine_set_weight(self.h, name.encode(), B.ptr(t), 0 if t.dtype == torch.bfloat16 else 1,
+                                                  t.numel()))
+            self._registered.add(name)
+        B.check(self.lib.vz_engine_finalize(self.h))
+        self.ready = True
+
+    # --------------------------------------------------------------------------------------------
+    # stages
+    # --------------------------------------------------------------------------------------------
+    def _s(self):
+        return B.stream_ptr(self.device)
+
+    def clip_fused_features(self, images: torch.Tensor, return_hidden: bool = False):
+        """images [T,3,336,336] -> bf16 [T,576,5*C]  (+ all hidden states [L+1,T,577,C] for tests)."""
+        cfg = self.cfg
+        if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != cfg.clip_image or images.shape[3] != cfg.clip_image:
+            raise ValueError(f"Input image size ({images.shape[-2]}*{images.shape[-1]}) doesn't match model "
+                             f"({cfg.clip_image}*{cfg.clip_image}).")
+        x = images.to(self.device, torch.bfloat16).contiguous()
+        T = x.shape[0]
+        out = torch.empty(T, cfg.clip_patches, (cfg.fusion_groups + 1) * cfg.clip_hidden, dtype=torch.bfloat16,
+                          device=self.device)
+        hid = None
+        if return_hidden:
+            hid = torch.empty(cfg.clip_layers + 1, T, cfg.clip_tokens, cfg.clip_hidden, dtype=torch.bfloat16,
+                              device=self.device)
+        B.check(self.lib.vz_clip_fused_features(self.h, B.ptr(x), T, B.ptr(out), B.ptr(hid), self._s()))
+        return (out, hid) if return_hidden else out
+
+    def qformer(self, feats: torch.Tensor, text: Optional[torch.Tensor], tile_sample: Sequence[int]):
+        """feats bf16 [T,576,5120]; text bf16 [n_samples,Lmax,H] or None; tile_sample[t] = sample of tile t."""
+        cfg = self.cfg
+        feats = feats.to(self.device, torch.bfloat16).contiguous()
+        T = feats.shape[0]
+        if text is not None and text.shape[1] == 0:
+            text = None
+        if text is not None:
+            text = text.to(self.device, torch.bfloat16).contiguous()
+            n_samples, Lmax = text.shape[0], text.shape[1]
+        else:
+            n_samples, Lmax = (max(tile_sample) + 1 if len(tile_sample) else 1), 0
+        ts = (C.c_int * T)(*[int(v) for v in tile_sample])
+        out = torch.empty(T, cfg.qf_queries, cfg.hidden, dtype=torch.bfloat16, device=self.device)
+        B.check(self.lib.vz_qformer(self.h, B.ptr(feats), T, B.ptr(text), n_samples, Lmax, ts, B.ptr(out), self._s()))
+        return out
+
+    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        ids32 = ids.to(self.device, torch.int32).contiguous().view(-1)
+        if ids32.numel() == 0:
+            return torch.empty(*ids.shape, self.cfg.hidden, dtype=torch.bfloat16, device=self.device)
+        if int(ids32.min()) < 0 or int(ids32.max()) >= self.cfg.vocab:
+            raise IndexError("token id out of range for embed_tokens")
+        out = torch.empty(ids32.numel(), self.cfg.hidden, dtype=torch.bfloat16, device=self.device)
+        B.check(self.lib.vz_embed_splice(self.h, None, B.ptr(ids32), ids32.numel(), None, B.ptr(out), self._s()))
+        return out.view(*ids.shape, self.cfg.hidden)
+
+    def splice(self, kind: torch.Tensor, idx: torch.Tensor, visual: Optional[torch.Tensor]) -> torch.Tensor:
+        """rows: kind 0 = embedding row idx, 1 = visual row idx, 2 = zero."""
+        kind = kind.to(self.device, torch.int32).contiguous()
+        idx = idx.to(self.device, torch.int32).contiguous()
+        out = torch.empty(kind.numel(), self.cfg.hidden, dtype=torch.bfloat16, device=self.device)
+        vis = None if visual is None else visual.to(torch.bfloat16).contiguous()
+        B.check(self.lib.vz_embed_splice(self.h, B.ptr(kind), B.ptr(idx), kind.numel(), B.ptr(vis), B.ptr(out), self._s()))
+        return out
+
+    def prefill(self, embeds: torch.Tensor, seqlens: Sequence[int], position_ids: Optional[torch.Tensor] = None,
+                all_logits: bool = False, last_logits: bool = True):
+        """embeds bf16 [B,S,H] right-padded.  Returns (logits_all fp32 [B,S,V] | None, logits_last fp32 [B,V] | None)."""
+        cfg = self.cfg
+        x = embeds.to(self.device, torch.bfloat16).contiguous()
+        Bn, S = x.shape[0], x.shape[1]
+        if position_ids is None:
+            position_ids = torch.arange(S, dtype=torch.int32, device=self.device).unsqueeze(0).expand(Bn, S)
+        pos = position_ids.to(self.device, torch.int32).contiguous()
+        la = torch.empty(Bn, S, cfg.vocab, dtype=torch.float32, device=self.device) if all_logits else None
+        ll = torch.empty(Bn, cfg.vocab, dtype=torch.float32, device=self.device) if last_logits else None
+        sl = (C.c_int * Bn)(*[int(v) for v in seqlens])
+        B.check(self.lib.vz_llm_prefill(self.h, B.ptr(x), Bn, S, sl, B.ptr(pos), B.ptr(la), B.ptr(ll), self._s()))
+        return la, ll
+
+    def decode_begin(self, first_ids: torch.Tensor, next_pos: Sequence[int], ctx_len: Sequence[int]):
+        ids = first_ids.to(self.device, torch.int32).contiguous().view(-1)
+        Bn = ids.numel()
+        np_ = (C.c_int * Bn)(*[int(v) for v in next_pos])
+        cl = (C.c_int * Bn)(*[int(v) for v in ctx_len])
+        self._dec_keep = ids
+        B.check(self.lib.vz_llm_decode_begin(self.h, Bn, B.ptr(ids), np_, cl, self._s()))
+        self._dec_B = Bn
+
+    def decode_steps(self, n: int, out: Optional[torch.Tensor] = None, return_logits: bool = False):
+        """enqueue n greedy steps; returns int32 [B,n] (device; no host sync) (+ fp32 logits [n,B,V])."""
+        Bn = self._dec_B
+        if out is None:
+            out = torch.empty(Bn, n, dtype=torch.int32, device=self.device)
+        lg = torch.empty(n, Bn, self.cfg.vocab, dtype=torch.float32, device=self.device) if return_logits else None
+        B.check(self.lib.vz_llm_decode_steps(self.h, n, B.ptr(out), B.ptr(lg), self._s()))
+        return (out, lg) if return_logits else out
+
+    # profiling hooks (bench.py roofline leg)
+    def prof_enable(self, on: bool, klass: int = -1):
+        B.check(self.lib.vz_prof_enable(self.h, int(on), klass))
+
+    def prof_read(self) -> Tuple[int, float]:
+        n, ms = C.c_long(), C.c_double()
+        B.check(self.lib.vz_prof_read(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
