@@ -215,7 +215,20 @@ def test_generate_greedy_matches_oracle_and_reference(env):
             break
     record("generate A", got=got[0].tolist(), oracle_bf16=ref_ids[0].tolist(), reference_fp32=g["A.generate.ids"][0].tolist(),
            min_margin=float(margin.min()))
-    assert got[0].tolist() == g["A.generate.ids"][0].tolist(), "generated ids differ from the reference's fp32 greedy ids"
+    # against the reference's own fp32 greedy ids (golden): identical up to the first step whose fp32 top-2 margin
+    # lies inside the measured bf16 logit band (random-weight logits have near-ties; after one the sequences
+    # legitimately diverge).  The band (max-norm, ~1.8e-2 of max|logit| on this model) is measured in
+    # test_forward_logits_case_a; 4e-2 = 2x that band + slack.
+    emb32 = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids, None, None, None, None, [tiles], P=O.FP32)[4]
+    ids32, lg32 = O.greedy_generate(cfg, sd, emb32, n_new, P=O.FP32, return_logits=True)
+    assert ids32[0].tolist() == g["A.generate.ids"][0].tolist()
+    t2 = lg32[0].topk(2, dim=-1).values
+    m32 = (t2[:, 0] - t2[:, 1]) / lg32[0].abs().amax(-1)
+    for t in range(n_new):
+        if int(got[0, t]) != int(ids32[0, t]):
+            assert float(m32[t]) < 4e-2, f"step {t}: differs from the fp32 reference although its margin is {float(m32[t]):.2e}"
+            break
+    assert got[0, 0].item() == int(g["A.generate.ids"][0, 0])
 
 
 def test_generate_text_only_and_callbacks(env):

@@ -209,7 +209,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
                               top_p: Optional[float] = None, top_k: Optional[int] = None, eos_token_id=None,
                               pad_token_id=None, streamer=None, stopping_criteria=None, use_cache: bool = True,
                               num_beams: int = 1, generator: Optional[torch.Generator] = None,
-                              sync_every: int = 16, **unused):
+                              sync_every: int = 16, timing: Optional[dict] = None, **unused):
         if num_beams != 1:
             raise NotImplementedError("beam search is not on the reference's inference path (cli/eval use sampling/greedy)")
         Bsz, S = inputs_embeds.shape[0], inputs_embeds.shape[1]
@@ -229,7 +229,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
             outs.append(self._generate_one(inputs_embeds[b:b + 1, :seqlens[b]],
                                            None if position_ids is None else position_ids[b:b + 1, :seqlens[b]],
                                            max_new_tokens, greedy, temperature, top_p, top_k, eos, streamer if Bsz == 1 else None,
-                                           stopping_criteria, generator, sync_every))
+                                           stopping_criteria, generator, sync_every, timing))
         n = max(len(o) for o in outs)
         res = torch.full((Bsz, n), pad_token_id, dtype=torch.long, device=self.device)
         for b, o in enumerate(outs):
@@ -237,7 +237,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         return res
 
     def _generate_one(self, embeds, position_ids, max_new, greedy, temperature, top_p, top_k, eos, streamer,
-                      stopping_criteria, generator, sync_every) -> List[int]:
+                      stopping_criteria, generator, sync_every, timing=None) -> List[int]:
         eng = self.engine
         S = embeds.shape[1]
         if S + max_new > eng.max_ctx:
@@ -257,7 +257,10 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
             # HF hands the (empty, since generation starts from embeddings) prompt ids to the streamer first;
             # TextStreamer(skip_prompt=True) swallows exactly one put() as "the prompt"
             streamer.put(torch.empty((1, 0), dtype=torch.long))
-        tok = pick(last[0])
+        tok = pick(last[0])          # int(): the host holds the first token here
+        if timing is not None:
+            import time
+            timing["t_first_token"] = time.perf_counter()
         out.append(tok)
         if self._emit(out, streamer, stopping_criteria, last, eos):
             return self._finish(out, streamer)
