@@ -102,6 +102,17 @@ int vz_op_attention_decode(const void* d_q, const void* d_kcache, const void* d_
                            int B, int Hq, int Hkv, int head_dim, int max_ctx, int nsplit, int window, float scale,
                            const int* d_ctx_len, vz_stream stream);
 
+/* The decode step's attention as the engine runs it: RoPE on the new token's Q/K, append of K/V to the cache,
+ * attention over the cache (4 query heads per KV head served from one pass over K/V) and the merge of the
+ * nsplit context slices, in ONE launch.  d_qkv bf16 [B,(Hq+2Hkv)*D] (un-rotated projection of the new token);
+ * d_pos / d_slot int32 [B] (position id, cache slot = tokens already cached); d_ticket uint32 [B*Hkv], zeroed
+ * once by the caller; d_workspace fp32 [B*Hkv*nsplit*4*(D+2)].  Same result as vz_op_rope_kv followed by
+ * vz_op_attention_decode. */
+int vz_op_attention_decode_fused(const void* d_qkv, void* d_kcache, void* d_vcache, void* d_o, float* d_workspace,
+                                 unsigned* d_ticket, const float* d_cos, const float* d_sin, const int* d_pos,
+                                 const int* d_slot, int B, int Hq, int Hkv, int head_dim, int max_ctx, int nsplit,
+                                 int window, float scale, vz_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * 2. Engine
  * ------------------------------------------------------------------------------------------ */
@@ -177,6 +188,10 @@ int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d_logits_dbg
 
 /* argmax over fp32 logits rows: ids int32 [rows] (first maximal index) */
 int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_stream stream);
+
+/* tuning hook for tools/bench_kernels.py: knob 0 = GEMV variant (0 = production choice, 1.. = alternatives
+ * compiled into the library: rows per wave, chunks in flight, non-temporal loads).  Process-wide. */
+int vz_tune_set(int knob, int value);
 
 /* per-kernel-class timing of the engine's launches with HIP events on the launch stream (bench.py's roofline
  * leg).  enable=1 disables graph replay and brackets every launch of class `klass` with events.

@@ -294,3 +294,30 @@ def test_attention_decode(B, ctx, nsplit, window):
         ref = _ref_attention(q[b:b + 1].unsqueeze(1), kc[b:b + 1, :, lo:n].permute(0, 2, 1, 3), vc[b:b + 1, :, lo:n].permute(0, 2, 1, 3),
                              D ** -0.5, False, 0, 0, None)
         check_close(f"attention decode ctx{n} b{b}", out[b], ref[0, 0], BF16_MAX, BF16_L2)
+
+
+@pytest.mark.parametrize("ctx,nsplit,window", [(1, 32, 0), (2, 4, 0), (77, 32, 0), (1500, 32, 0), (2047, 32, 4096), (700, 16, 256),
+                                               (3000, 8, 0)])
+def test_attention_decode_fused_equals_rope_plus_decode(B, ctx, nsplit, window):
+    """the engine's one-launch decode attention (RoPE + append + split attention + in-launch combine) against the
+    two-kernel path, twice in a row on the same ticket buffer (graph replays reuse it)."""
+    Bn, Hq, Hkv, D, max_ctx = 2, 32, 8, 128, 3072
+    kc = _rand((Bn, Hkv, max_ctx, D), 1.0, 50).bfloat16()
+    vc = _rand((Bn, Hkv, max_ctx, D), 1.0, 51).bfloat16()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))
+    fr = torch.arange(max_ctx + 8, dtype=torch.float32).unsqueeze(-1) * inv
+    cos, sin = fr.cos().cuda().contiguous(), fr.sin().cuda().contiguous()
+    ticket = None
+    for rep in range(2):
+        slot = torch.tensor([ctx - 1 + rep, max(0, ctx // 2 - 1) + rep], dtype=torch.int32, device="cuda")
+        pos = slot + 5
+        qkv = _rand((Bn, (Hq + 2 * Hkv) * D), 1.0, 52 + rep).bfloat16()
+        kc1, vc1 = kc.clone(), vc.clone()
+        q = B.rope_kv(qkv, cos, sin, pos, slot, kc1, vc1, Bn, 1, Hq, Hkv, D)
+        ref = B.attention_decode(q.view(Bn, Hq, D), kc1, vc1, slot + 1, D ** -0.5, 8, window)
+        kc2, vc2 = kc.clone(), vc.clone()
+        out, ticket = B.attention_decode_fused(qkv, kc2, vc2, cos, sin, pos, slot, Hq, D ** -0.5, nsplit, window, ticket)
+        assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2), "cache append differs"
+        check_close(f"fused decode attention ctx{ctx} rep{rep}", out, ref.float(), 8e-3, 2e-3)
+        assert int(ticket.abs().sum()) == 0, "ticket not reset by the last arriver"
+        kc, vc = kc2, vc2

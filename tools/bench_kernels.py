@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmarks on the GPU box (one process, interleaved rounds, random data; cdna guide rule 24/25).
+
+    python tools/bench_kernels.py gemv|gemm|attn|all
+
+Weights cycle through a pool larger than the 256 MiB Infinity Cache so every launch streams from HBM,
+as the real decode step does (14 GB of weights per token)."""
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "vision-zephyr_amd"))
+import torch  # noqa: E402
+
+from vz_hip import binding as B  # noqa: E402
+
+dev = "cuda"
+
+
+def timed(fn, n_iter, warm=3):
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(n_iter):
+        fn(i)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n_iter * 1e3   # us
+
+
+def bench_gemv():
+    shapes = [("qkv+norm", 6144, 4096, 0), ("o", 4096, 4096, 0), ("gate-up swiglu", 28672, 4096, 3), ("down", 4096, 14336, 0),
+              ("lm_head fp32", 32000, 4096, 0)]
+    res = {}
+    for name, N, K, act in shapes:
+        pool = max(2, int(1.2e9 // (N * K * 2)))
+        ws = [torch.randn(N, K, device=dev).bfloat16() * 0.02 for _ in range(pool)]
+        x = torch.randn(1, K, device=dev).bfloat16()
+        out32 = "fp32" in name
+        rows = {}
+        # prepared ctypes argument tuples: ~3 us of host time per launch, far below the kernels' 8-60 us
+        n_out = N // 2 if act == 3 else N
+        out = torch.empty(1, n_out, dtype=torch.float32 if out32 else torch.bfloat16, device=dev)
+        st = B.stream_ptr()
+        fn = B.lib().vz_op_linear_impl
+        argl = [(1, B.ptr(x), K, B.ptr(w), K, B.ptr(out), n_out, 1, N, K, None, None, 0, act, int(out32), st) for w in ws]
+        for rnd in range(3):
+            for v in (1, 2, 3, 4, 5, 6):
+                B.check(B.lib().vz_tune_set(0, v))
+                us = timed(lambda i: fn(*argl[i % pool]), 6 * pool)
+                rows.setdefault(v, []).append(us)
+        B.check(B.lib().vz_tune_set(0, 0))
+        mb = N * K * 2 / 1e6
+        res[name] = {v: (min(t), mb / min(t) * 1e6 / 1e9) for v, t in rows.items()}
+        print(f"gemv {name:16s} {mb:7.1f} MB: " + "  ".join(f"v{v}: {min(t):6.1f}us {mb / min(t):5.2f}TB/s" for v, t in rows.items()), flush=True)
+        del ws
+    return res
+
+
+def bench_gemm():
+    shapes = [("llm qkv", 2048, 6144, 4096, 0), ("llm o", 2048, 4096, 4096, 0), ("llm gate-up", 2048, 28672, 4096, 3),
+              ("llm down", 2048, 4096, 14336, 0), ("clip qkv", 2885, 3072, 1024, 0), ("clip fc1", 2885, 4096, 1024, 1),
+              ("clip fc2", 2885, 1024, 4096, 0), ("qf ca_kv", 2880, 8192, 5120, 0), ("qf small", 160, 4096, 4096, 0),
+              ("qf ffn1", 160, 8192, 4096, 2), ("qf blk0 kv", 1920, 8192, 4096, 0)]
+    for name, M, N, K, act in shapes:
+        x = torch.randn(M, K, device=dev).bfloat16()
+        ws = [torch.randn(N, K, device=dev).bfloat16() * 0.02 for _ in range(3)]
+        us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act, impl=0), 12) for _ in range(3))
+        tf = 2.0 * M * N * K / us / 1e6
+        print(f"gemm {name:12s} M{M} N{N} K{K}: {us:8.1f} us  {tf:7.1f} TFLOP/s ({tf / 2500 * 100:4.1f}% of 2.5 PF)", flush=True)
+
+
+def bench_attn():
+    S, Hq, Hkv, D = 2048, 32, 8, 128
+    q = torch.randn(1, S, Hq, D, device=dev).bfloat16()
+    k = torch.randn(1, S, Hkv, D, device=dev).bfloat16()
+    v = torch.randn(1, S, Hkv, D, device=dev).bfloat16()
+    us = min(timed(lambda i: B.attention(q, k, v, D ** -0.5, True, 0, 4096), 10) for _ in range(3))
+    fl = 4.0 * S * S * D * Hq / 2
+    print(f"attn prefill causal S{S}: {us:8.1f} us  {fl / us / 1e6:6.1f} TFLOP/s", flush=True)
+    T = 5
+    qkv = torch.randn(T, 577, 3 * 1024, device=dev).bfloat16()
+    us = min(timed(lambda i: B.attention(qkv[:, :, :1024].view(T, 577, 16, 64), qkv[:, :, 1024:2048].view(T, 577, 16, 64),
+                                         qkv[:, :, 2048:].view(T, 577, 16, 64), 0.125), 10) for _ in range(3))
+    print(f"attn clip T{T}: {us:8.1f} us  {4.0 * 577 * 577 * 64 * 16 * T / us / 1e6:6.1f} TFLOP/s", flush=True)
+    # decode attention at ctx 2048: fused vs two-kernel
+    max_ctx = 2304
+    kc = torch.randn(1, Hkv, max_ctx, D, device=dev).bfloat16()
+    vc = torch.randn(1, Hkv, max_ctx, D, device=dev).bfloat16()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))
+    fr = torch.arange(max_ctx, dtype=torch.float32).unsqueeze(-1) * inv
+    cos, sin = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
+    qkv1 = torch.randn(1, (Hq + 2 * Hkv) * D, device=dev).bfloat16()
+    slot = torch.tensor([2047], dtype=torch.int32, device=dev)
+    ticket = torch.zeros(Hkv, dtype=torch.int32, device=dev)
+    for ns in (8, 16, 32, 64):
+        us = min(timed(lambda i: B.attention_decode_fused(qkv1, kc, vc, cos, sin, slot, slot, Hq, D ** -0.5, ns, 4096, ticket), 50)
+                 for _ in range(3))
+        print(f"attn decode fused ctx2048 nsplit{ns}: {us:7.1f} us  ({2 * Hkv * 2048 * 256 / us / 1e3:6.1f} GB/s of KV)", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    torch.manual_seed(0)
+    if what in ("gemv", "all"):
+        bench_gemv()
+    if what in ("gemm", "all"):
+        bench_gemm()
+    if what in ("attn", "all"):
+        bench_attn()

@@ -26,6 +26,7 @@
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
+thread_local hipEvent_t g_vz_prof_start = nullptr, g_vz_prof_stop = nullptr;
 static thread_local char g_err[1024] = "";
 void vz_set_error(const char* fmt, ...) {
     va_list ap;
@@ -97,6 +98,16 @@ extern "C" int vz_op_attention_decode(const void* q, const void* kc, const void*
     a.ctx_len = ctx_len;
     return vz_launch_attn_decode(a, (hipStream_t)s);
 }
+extern "C" int vz_op_attention_decode_fused(const void* qkv, void* kc, void* vc, void* o, float* ws, unsigned* ticket,
+                                            const float* cosT, const float* sinT, const int* pos, const int* slot, int B, int Hq,
+                                            int Hkv, int D, int max_ctx, int nsplit, int window, float scale, vz_stream s) {
+    VZ_CHECK_ARG(qkv && kc && vc && o && ws && ticket && cosT && sinT && pos && slot && B > 0, "attention_decode_fused: bad argument");
+    AttnDecodeFusedArgs a;
+    a.qkv = (const bf16_t*)qkv; a.kc = (bf16_t*)kc; a.vc = (bf16_t*)vc; a.o = (bf16_t*)o; a.part = ws; a.ticket = ticket;
+    a.cosT = cosT; a.sinT = sinT; a.pos = pos; a.slot = slot;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_ctx = max_ctx; a.nsplit = nsplit; a.window = window; a.scale = scale;
+    return vz_launch_attn_decode_fused(a, (hipStream_t)s);
+}
 extern "C" int vz_op_argmax(const float* logits, int rows, int cols, int* ids, vz_stream s) {
     return vz_launch_argmax(logits, rows, cols, ids, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (hipStream_t)s);
 }
@@ -123,6 +134,7 @@ struct vz_engine {
     int dec_B = 0;
     float* d_logits = nullptr;   // [max_batch, vocab] fp32
     float* d_part = nullptr;     // decode attention partials
+    unsigned* d_ticket = nullptr; // arrival counters of the fused decode attention
     int nsplit = 16;
     hipStream_t cap_stream = nullptr;   // stream capture is not allowed on the legacy null stream torch hands us
     hipGraphExec_t dec_graph = nullptr; int dec_graph_B = 0, dec_graph_n = 0; int* dec_graph_out = nullptr; char* dec_graph_arena = nullptr;
@@ -149,7 +161,7 @@ static const void* W_(vz_engine* e, const std::string& name, int dtype, long n, 
 #define RC(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
 struct ProfScope {
-    vz_engine* e; hipStream_t s; bool on; size_t idx;
+    vz_engine* e; hipStream_t s; bool on; size_t idx; bool ext = false;
     ProfScope(vz_engine* e_, int klass, hipStream_t s_) : e(e_), s(s_), on(false), idx(0) {
         if (e->prof_on && klass == e->prof_class) {
             if (e->prof_used == e->prof_ev.size()) {
@@ -159,10 +171,23 @@ struct ProfScope {
             }
             idx = e->prof_used++;
             on = true;
-            hipEventRecord(e->prof_ev[idx].first, s);
+            if (klass == K_GEMM || klass == K_GEMV) {      // stamped by the launch itself (kernel-only duration)
+                g_vz_prof_start = e->prof_ev[idx].first;
+                g_vz_prof_stop = e->prof_ev[idx].second;
+                ext = true;
+            } else {
+                (void)hipEventRecord(e->prof_ev[idx].first, s);
+            }
         }
     }
-    ~ProfScope() { if (on) hipEventRecord(e->prof_ev[idx].second, s); }
+    ~ProfScope() {
+        if (!on) return;
+        if (ext) {
+            if (g_vz_prof_start) { g_vz_prof_start = nullptr; g_vz_prof_stop = nullptr; e->prof_used--; }   // launch never happened
+        } else {
+            (void)hipEventRecord(e->prof_ev[idx].second, s);
+        }
+    }
 };
 
 static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M,
@@ -233,6 +258,8 @@ extern "C" int vz_engine_create(const vz_config* cfg, vz_engine** out) {
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_state, (4 * c.max_batch + 4) * sizeof(int));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_logits, (size_t)c.max_batch * c.vocab * sizeof(float));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_part, (size_t)c.max_batch * c.n_heads * 64 * (128 + 2) * sizeof(float));
+    if (er == hipSuccess) er = hipMalloc((void**)&e->d_ticket, 4096);
+    if (er == hipSuccess) er = hipMemset(e->d_ticket, 0, 4096);
     if (er != hipSuccess) {
         vz_set_error("engine_create: hipMalloc failed: %s", hipGetErrorString(er));
         delete e;
@@ -253,6 +280,7 @@ extern "C" int vz_engine_destroy(vz_engine* e) {
     if (e->d_state) hipFree(e->d_state);
     if (e->d_logits) hipFree(e->d_logits);
     if (e->d_part) hipFree(e->d_part);
+    if (e->d_ticket) hipFree(e->d_ticket);
     if (e->h_pinned) hipHostFree(e->h_pinned);
     delete e;
     return VZ_OK;
@@ -624,7 +652,6 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
     Carver m(e->arena, e->arena_bytes);
     bf16_t* x = m.take<bf16_t>((size_t)B * H);
     bf16_t* qkv = m.take<bf16_t>((size_t)B * QKV);
-    bf16_t* q = m.take<bf16_t>((size_t)B * H);
     bf16_t* att = m.take<bf16_t>((size_t)B * H);
     bf16_t* act = m.take<bf16_t>((size_t)B * I);
     if (!m.ok) { vz_set_error("decode: workspace too small"); return VZ_ERR_STATE; }
@@ -633,14 +660,14 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
     for (int i = 0; i < c.n_layers; ++i) {
         const std::string p = "llm." + std::to_string(i) + ".";
         RC(linear(e, 0, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps));
-        { ProfScope ps(e, K_OTHER, s); RC(vz_launch_rope_kv(qkv, QKV, q, kc_of(e, i), vc_of(e, i), e->cosT, e->sinT, pos, slot, B, 1, Hq, Hkv, D, c.max_ctx, s)); }
         {
             ProfScope ps(e, K_ATTN_DEC, s);
-            AttnDecodeArgs a;
-            a.q = q; a.kc = kc_of(e, i); a.vc = vc_of(e, i); a.o = att; a.part = e->d_part;
+            AttnDecodeFusedArgs a;
+            a.qkv = qkv; a.kc = kc_of(e, i); a.vc = vc_of(e, i); a.o = att; a.part = e->d_part; a.ticket = e->d_ticket;
+            a.cosT = e->cosT; a.sinT = e->sinT; a.pos = pos; a.slot = slot;
             a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_ctx = c.max_ctx; a.nsplit = e->nsplit; a.window = c.sliding_window;
-            a.scale = 0.08838834764831845f; a.ctx_len = len;
-            RC(vz_launch_attn_decode(a, s));
+            a.scale = 0.08838834764831845f;
+            RC(vz_launch_attn_decode_fused(a, s));
         }
         RC(linear(e, 0, att, H, WB(p + "o.w", (long)H * H), H, x, H, B, H, H, nullptr, x, H, VZ_ACT_NONE, 0, s));
         RC(linear(e, 0, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps));
@@ -694,6 +721,12 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     }
     for (int i = 0; i < n; ++i) VZ_CHECK_HIP(hipGraphLaunch(e->dec_graph, s));
     return VZ_OK;
+}
+
+extern "C" int vz_tune_set(int knob, int value) {
+    if (knob == 0) { vz_set_gemv_variant(value); return VZ_OK; }
+    vz_set_error("tune_set: unknown knob %d", knob);
+    return VZ_ERR_ARG;
 }
 
 extern "C" int vz_prof_enable(vz_engine* e, int enable, int klass) {

@@ -182,122 +182,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// GEMV (M <= 8)
-// ------------------------------------------------------------------------------------------------
-struct GemvParams {
-    const bf16_t* A; const bf16_t* W; void* C;
-    const float* bias; const bf16_t* residual; const float* norm_w;
-    int M, N, K, lda, ldw, ldc, ldr;
-    int act, out_fp32, units;
-    float norm_eps;
-};
+}  // namespace
 
-__device__ __forceinline__ float dot8(const uint4& w, const uint4& x, float acc) {
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.x), __builtin_bit_cast(bf16x2, x.x), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.y), __builtin_bit_cast(bf16x2, x.y), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.z), __builtin_bit_cast(bf16x2, x.z), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.w), __builtin_bit_cast(bf16x2, x.w), acc, false);
-    return acc;
-}
-
-template <int MB>
-__global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // xs[MB][K] bf16, then 16 floats of scratch
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = p.K;
-    float* red = (float*)(smem + (size_t)MB * K * 2);
-
-    // ---- prologue: x (optionally RMS-normalised) -> LDS as bf16 ----
-    for (int m = 0; m < MB; ++m) {
-        bf16_t* xs = (bf16_t*)smem + (size_t)m * K;
-        if (m >= p.M) {
-            for (int k = tid * 8; k < K; k += 256 * 8) *(uint4*)(xs + k) = make_uint4(0, 0, 0, 0);
-            continue;
-        }
-        const bf16_t* x = p.A + (size_t)m * p.lda;
-        if (p.norm_w) {
-            float ss = 0.f;
-            for (int k = tid * 8; k < K; k += 256 * 8) {
-                const u16x8 v = *(const u16x8*)(x + k);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(v[j]); ss += f * f; }
-            }
-            ss = wave_sum(ss);
-            __syncthreads();
-            if (lane == 0) red[wave] = ss;
-            __syncthreads();
-            const float tot = red[0] + red[1] + red[2] + red[3];
-            const float rstd = rsqrtf(tot / (float)K + p.norm_eps);
-            for (int k = tid * 8; k < K; k += 256 * 8) {
-                const u16x8 v = *(const u16x8*)(x + k);
-                const f32x4 w0 = *(const f32x4*)(p.norm_w + k), w1 = *(const f32x4*)(p.norm_w + k + 4);
-                u16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float wj = j < 4 ? w0[j] : w1[j - 4];
-                    o[j] = f32_to_bf16(wj * (bf16_to_f32(v[j]) * rstd));
-                }
-                *(u16x8*)(xs + k) = o;
-            }
-        } else {
-            for (int k = tid * 8; k < K; k += 256 * 8) *(uint4*)(xs + k) = *(const uint4*)(x + k);
-        }
-    }
-    __syncthreads();
-
-    const bool swiglu = p.act == VZ_ACT_SWIGLU;
-    const int nchunk = K >> 9;  // 512 elements (1 KiB) per wave-instruction
-    for (int u = blockIdx.x * 4 + wave; u < p.units; u += gridDim.x * 4) {
-        int r0, r1;
-        if (swiglu) { r0 = (u >> 4) * 32 + (u & 15); r1 = r0 + 16; }
-        else { r0 = 2 * u; r1 = r0 + 1 < p.N ? r0 + 1 : r0; }
-        const bf16_t* w0p = p.W + (size_t)r0 * p.ldw + lane * 8;
-        const bf16_t* w1p = p.W + (size_t)r1 * p.ldw + lane * 8;
-        float a0[MB], a1[MB];
-#pragma unroll
-        for (int m = 0; m < MB; ++m) { a0[m] = 0.f; a1[m] = 0.f; }
-#pragma unroll 4
-        for (int c = 0; c < nchunk; ++c) {
-            const uint4 w0 = *(const uint4*)(w0p + c * 512);
-            const uint4 w1 = *(const uint4*)(w1p + c * 512);
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                const uint4 xv = *(const uint4*)((const bf16_t*)smem + (size_t)m * K + c * 512 + lane * 8);
-                a0[m] = dot8(w0, xv, a0[m]);
-                a1[m] = dot8(w1, xv, a1[m]);
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MB; ++m) { a0[m] = wave_sum(a0[m]); a1[m] = wave_sum(a1[m]); }
-        if (lane == 0) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                if (m >= p.M) break;
-                if (swiglu) {
-                    float t = act_silu(a0[m]) * a1[m];
-                    if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + u]);
-                    if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + u] = t;
-                    else ((bf16_t*)p.C)[(size_t)m * p.ldc + u] = f32_to_bf16(t);
-                } else {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int n = 2 * u + h;
-                        if (n >= p.N) break;
-                        float t = h ? a1[m] : a0[m];
-                        if (p.bias) t += p.bias[n];
-                        t = apply_act(t, p.act);
-                        if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + n]);
-                        if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + n] = t;
-                        else ((bf16_t*)p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(t);
-                    }
-                }
-            }
-        }
-    }
-}
-
-int check_common(const LinearArgs& a) {
+int vz_linear_check_common(const LinearArgs& a) {
     VZ_CHECK_ARG(a.A && a.W && a.C, "linear: null pointer");
     VZ_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "linear: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     VZ_CHECK_ARG(a.K % 64 == 0, "linear: K=%d must be a multiple of 64", a.K);
@@ -316,22 +203,17 @@ int check_common(const LinearArgs& a) {
     return VZ_OK;
 }
 
-}  // namespace
-
 int vz_init_gemm_kernels() {
     static bool done = false;
     if (done) return VZ_OK;
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    { int r = vz_init_gemv_kernels(); if (r) return r; }
     done = true;
     return VZ_OK;
 }
 
 int vz_launch_gemm(const LinearArgs& a, hipStream_t s) {
-    int rc = check_common(a);
+    int rc = vz_linear_check_common(a);
     if (rc) return rc;
     VZ_CHECK_ARG(!a.norm_w, "linear: fused RMSNorm prologue exists on the GEMV path only");
     GemmParams p;
@@ -341,45 +223,12 @@ int vz_launch_gemm(const LinearArgs& a, hipStream_t s) {
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;
     { int r = vz_init_gemm_kernels(); if (r) return r; }
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), GEMM_LDS, s, p);
-    VZ_LAUNCH_CHECK();
-    return VZ_OK;
-}
-
-static bool gemv_ok(const LinearArgs& a) {
-    if (a.M > 8 || (a.K % 512) != 0) return false;
-    int mb = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
-    return (size_t)mb * a.K * 2 + 64 <= 64 * 1024;
-}
-
-int vz_launch_gemv(const LinearArgs& a, hipStream_t s) {
-    int rc = check_common(a);
-    if (rc) return rc;
-    VZ_CHECK_ARG(gemv_ok(a), "gemv: needs M <= 8, K %% 512 == 0 and M*K*2 <= 64 KiB (M=%d K=%d)", a.M, a.K);
-    GemvParams p;
-    p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.residual = a.residual; p.norm_w = a.norm_w;
-    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr;
-    p.act = a.act; p.out_fp32 = a.out_fp32; p.norm_eps = a.norm_eps;
-    p.units = a.act == VZ_ACT_SWIGLU ? a.N / 2 : (a.N + 1) / 2;
-    int blocks = (p.units + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    const int mb = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
-    const size_t lds = (size_t)mb * a.K * 2 + 64;
-    { int r = vz_init_gemm_kernels(); if (r) return r; }
-#define VZ_GEMV_CASE(MB) \
-    case MB: hipLaunchKernelGGL(gemv_bf16_kernel<MB>, dim3(blocks), dim3(256), lds, s, p); break;
-    switch (mb) {
-        VZ_GEMV_CASE(1)
-        VZ_GEMV_CASE(2)
-        VZ_GEMV_CASE(4)
-        VZ_GEMV_CASE(8)
-    }
-#undef VZ_GEMV_CASE
+    vz_launch_timed(gemm_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), GEMM_LDS, s, p);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
 
 int vz_launch_linear(const LinearArgs& a, hipStream_t s) {
-    if (gemv_ok(a)) return vz_launch_gemv(a, s);
+    if (vz_gemv_ok(a)) return vz_launch_gemv(a, s);
     return vz_launch_gemm(a, s);
 }

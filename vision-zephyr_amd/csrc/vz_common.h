@@ -81,6 +81,24 @@ struct LinearArgs {
     const float* norm_w; float norm_eps;
 };
 int vz_launch_gemm(const LinearArgs& a, hipStream_t s);
+int vz_linear_check_common(const LinearArgs& a);
+bool vz_gemv_ok(const LinearArgs& a);
+int vz_init_gemv_kernels();
+void vz_set_gemv_variant(int v);
+// Profiling: when set, the next GEMM/GEMV launch is issued through hipExtLaunchKernelGGL with these events, which
+// the runtime stamps at the kernel's own start and end on the GPU (no launch gap inside the bracket).
+extern thread_local hipEvent_t g_vz_prof_start, g_vz_prof_stop;
+#include <hip/hip_ext.h>
+template <typename F, typename... Args>
+inline void vz_launch_timed(F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+    if (g_vz_prof_start) {
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, s, g_vz_prof_start, g_vz_prof_stop, 0, args...);
+        g_vz_prof_start = nullptr;
+        g_vz_prof_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+    }
+}
 int vz_launch_gemv(const LinearArgs& a, hipStream_t s);
 int vz_launch_linear(const LinearArgs& a, hipStream_t s);  // picks by M
 
@@ -112,6 +130,19 @@ struct AttnDecodeArgs {
     const int* ctx_len;   // device int32 [B]: keys visible to this step (incl. the token just appended)
 };
 int vz_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
+
+// decode attention with RoPE + KV append + split combine fused into one launch (attn_decode.hip)
+struct AttnDecodeFusedArgs {
+    const bf16_t* qkv;     // [B, (Hq+2Hkv)*D]
+    bf16_t *kc, *vc, *o;   // caches for this layer [B][Hkv][max_ctx][D]; o [B,Hq,D]
+    float* part;           // [B*Hkv*nsplit*4*(D+2)]
+    unsigned* ticket;      // [B*Hkv], zeroed once
+    const float *cosT, *sinT;
+    const int *pos, *slot; // device int32 [B]
+    int B, Hq, Hkv, D, max_ctx, nsplit, window;
+    float scale;
+};
+int vz_launch_attn_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s);
 
 int vz_launch_rope_kv(const bf16_t* qkv, int ld, bf16_t* q_out, bf16_t* kc, bf16_t* vc, const float* cosT,
                       const float* sinT, const int* pos, const int* slot, int B, int S, int Hq, int Hkv, int D,

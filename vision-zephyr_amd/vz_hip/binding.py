@@ -49,6 +49,7 @@ SYMBOLS = {
     "vz_op_argmax": (_I, [_P, _I, _I, _P, _P]),
     "vz_op_rope_kv": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vz_op_attention_decode": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "vz_op_attention_decode_fused": (_I, [_P] * 10 + [_I] * 7 + [_F, _P]),
     "vz_engine_create": (_I, [C.POINTER(VzConfig), C.POINTER(_P)]),
     "vz_engine_destroy": (_I, [_P]),
     "vz_engine_set_weight": (_I, [_P, C.c_char_p, _P, _I, _L]),
@@ -60,6 +61,7 @@ SYMBOLS = {
     "vz_llm_prefill": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int), _P, _P, _P, _P]),
     "vz_llm_decode_begin": (_I, [_P, _I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
+    "vz_tune_set": (_I, [_I, _I]),
     "vz_prof_enable": (_I, [_P, _I, _I]),
     "vz_prof_read": (_I, [_P, C.POINTER(C.c_long), C.POINTER(C.c_double)]),
 }
@@ -207,3 +209,17 @@ def attention_decode(q, kcache, vcache, ctx_len, scale, nsplit=8, window=0):
     check(lib().vz_op_attention_decode(ptr(q), ptr(kcache), ptr(vcache), ptr(o), ptr(ws), Bn, Hq, kcache.shape[1], D,
                                        kcache.shape[2], nsplit, window, float(scale), ptr(ctx_len), stream_ptr(q.device)))
     return o
+
+
+def attention_decode_fused(qkv, kcache, vcache, cos, sin, pos, slot, Hq, scale, nsplit=32, window=0, ticket=None):
+    """qkv bf16 [B,(Hq+2Hkv)*D] -> o [B,Hq,D]; appends the new K/V rows to the caches in place."""
+    _need_cuda(qkv, kcache, vcache, cos, sin, pos, slot)
+    Bn, Hkv, max_ctx, D = kcache.shape
+    ws = torch.empty(Bn * Hkv * nsplit * 4 * (D + 2), dtype=torch.float32, device=qkv.device)
+    if ticket is None:
+        ticket = torch.zeros(Bn * Hkv, dtype=torch.int32, device=qkv.device)
+    o = torch.empty(Bn, Hq, D, dtype=torch.bfloat16, device=qkv.device)
+    check(lib().vz_op_attention_decode_fused(ptr(qkv), ptr(kcache), ptr(vcache), ptr(o), ptr(ws), ptr(ticket), ptr(cos),
+                                             ptr(sin), ptr(pos), ptr(slot), Bn, Hq, Hkv, D, max_ctx, nsplit, window,
+                                             float(scale), stream_ptr(qkv.device)))
+    return o, ticket
