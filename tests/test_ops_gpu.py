@@ -321,3 +321,45 @@ def test_attention_decode_fused_equals_rope_plus_decode(B, ctx, nsplit, window):
         check_close(f"fused decode attention ctx{ctx} rep{rep}", out, ref.float(), 8e-3, 2e-3)
         assert int(ticket.abs().sum()) == 0, "ticket not reset by the last arriver"
         kc, vc = kc2, vc2
+
+
+GEMM256_SHAPES = [(2048, 6144, 4096), (2048, 4096, 14336), (2885, 4096, 1024), (300, 520, 128), (256, 256, 64), (257, 255, 192),
+                  (1, 32001, 512), (2048, 28672, 4096)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM256_SHAPES)
+def test_gemm256_bit_identical_to_gemm128(B, M, N, K):
+    """The 8-phase 256x256 kernel accumulates K in the same order as the 128x128 kernel, so fp32 outputs must be
+    BIT-IDENTICAL.  Any LDS-DMA tile read before it landed (RAW) or overwritten too early (WAR) breaks equality, so
+    the comparison is repeated under different machine states (back-to-back launches, other kernels in between)."""
+    x = _rand((M, K), 1.0, 60).bfloat16()
+    w = _rand((N, K), 0.05, 61).bfloat16()
+    ref = B.linear(x, w, out_fp32=True, impl=0)
+    check_close(f"gemm128 ref {M}x{N}x{K}", ref, _ref_linear(x, w, None, None, 0), 1e-4, 1e-4)
+    for rep in range(6):
+        if rep % 2:
+            torch.randn(1 << 22, device="cuda").sum()          # perturb caches / clocks between launches
+        out = B.linear(x, w, out_fp32=True, impl=2)
+        assert torch.equal(out, ref), f"rep {rep}: {(out != ref).sum().item()} elements differ, max {float((out - ref).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm256_epilogues(B, act):
+    M, N, K = 700, 1024, 1024
+    x = _rand((M, K), 1.0, 62).bfloat16()
+    w = _rand((N, K), 0.05, 63).bfloat16()
+    bias = None if act == 3 else _rand((N,), 0.5, 64)
+    n_out = N // 2 if act == 3 else N
+    res = _rand((M, n_out), 1.0, 65).bfloat16()
+    out = B.linear(x, w, bias=bias, residual=res, act=act, impl=2)
+    ref128 = B.linear(x, w, bias=bias, residual=res, act=act, impl=0)
+    check_close(f"gemm256 epilogue act{act}", out, _ref_linear(x, w, bias, res, act), BF16_MAX, BF16_L2)
+    assert torch.equal(out, ref128)
+
+
+def test_gemm256_identity_asymmetric(B):
+    K = 256
+    x = torch.eye(K, device="cuda").bfloat16()
+    w = (torch.arange(384 * K, device="cuda").view(384, K) % 251 - 125).float().bfloat16()
+    out = B.linear(x, w, out_fp32=True, impl=2)
+    assert torch.equal(out, w.float().t().contiguous())

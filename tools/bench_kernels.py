@@ -69,9 +69,12 @@ def bench_gemm():
     for name, M, N, K, act in shapes:
         x = torch.randn(M, K, device=dev).bfloat16()
         ws = [torch.randn(N, K, device=dev).bfloat16() * 0.02 for _ in range(3)]
-        us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act, impl=0), 12) for _ in range(3))
-        tf = 2.0 * M * N * K / us / 1e6
-        print(f"gemm {name:12s} M{M} N{N} K{K}: {us:8.1f} us  {tf:7.1f} TFLOP/s ({tf / 2500 * 100:4.1f}% of 2.5 PF)", flush=True)
+        row = []
+        for impl in (0, 2):
+            us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act, impl=impl), 12) for _ in range(3))
+            tf = 2.0 * M * N * K / us / 1e6
+            row.append(f"{'128' if impl == 0 else '256'}: {us:8.1f} us {tf:7.1f} TF ({tf / 2500 * 100:4.1f}%)")
+        print(f"gemm {name:12s} M{M} N{N} K{K}: " + "   ".join(row), flush=True)
 
 
 def bench_attn():

@@ -58,8 +58,9 @@ extern "C" int vz_op_linear_impl(int impl, const void* A, int lda, const void* W
                                  int K, const float* bias, const void* residual, int ldr, int act, int out_fp32,
                                  vz_stream s) {
     LinearArgs a = mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, act, out_fp32);
-    if (impl == 0) return vz_launch_gemm(a, (hipStream_t)s);
+    if (impl == 0) return vz_launch_gemm128(a, (hipStream_t)s);
     if (impl == 1) return vz_launch_gemv(a, (hipStream_t)s);
+    if (impl == 2) return vz_launch_gemm256(a, (hipStream_t)s);
     vz_set_error("linear: unknown impl %d", impl);
     return VZ_ERR_ARG;
 }
@@ -725,6 +726,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
 
 extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 0) { vz_set_gemv_variant(value); return VZ_OK; }
+    if (knob == 1) { vz_set_gemm_choice(value); return VZ_OK; }
     vz_set_error("tune_set: unknown knob %d", knob);
     return VZ_ERR_ARG;
 }

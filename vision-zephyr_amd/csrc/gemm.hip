@@ -207,12 +207,24 @@ int vz_init_gemm_kernels() {
     static bool done = false;
     if (done) return VZ_OK;
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-    { int r = vz_init_gemv_kernels(); if (r) return r; }
+    { int r = vz_init_gemv_kernels(); if (r) return r; r = vz_init_gemm256_kernel(); if (r) return r; }
     done = true;
     return VZ_OK;
 }
 
+static int g_gemm_choice = 0;
+void vz_set_gemm_choice(int v) { g_gemm_choice = v; }
+
+// Tile choice: the 256x256 8-phase kernel runs one workgroup per CU, so it needs enough 256^2 tiles to fill the
+// 256 CUs several times over (>= 512 tiles: measured cross-over on MI355X, tools/bench_kernels.py); smaller grids keep the
+// 128x128 kernel (2 workgroups per CU, 4x the tiles).
 int vz_launch_gemm(const LinearArgs& a, hipStream_t s) {
+    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const bool use256 = g_gemm_choice == 2 || (g_gemm_choice == 0 && t256 >= 512);
+    return use256 ? vz_launch_gemm256(a, s) : vz_launch_gemm128(a, s);
+}
+
+int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
     int rc = vz_linear_check_common(a);
     if (rc) return rc;
     VZ_CHECK_ARG(!a.norm_w, "linear: fused RMSNorm prologue exists on the GEMV path only");

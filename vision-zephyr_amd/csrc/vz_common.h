@@ -100,6 +100,10 @@ inline void vz_launch_timed(F kernel, dim3 grid, dim3 block, size_t lds, hipStre
     }
 }
 int vz_launch_gemv(const LinearArgs& a, hipStream_t s);
+int vz_launch_gemm128(const LinearArgs& a, hipStream_t s);
+int vz_launch_gemm256(const LinearArgs& a, hipStream_t s);
+int vz_init_gemm256_kernel();
+void vz_set_gemm_choice(int v);   // 0 auto, 1 force 128x128, 2 force 256x256
 int vz_launch_linear(const LinearArgs& a, hipStream_t s);  // picks by M
 
 int vz_launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const float* w, const float* b, int rows,
