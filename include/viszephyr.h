@@ -106,7 +106,7 @@ int vz_op_attention_decode(const void* d_q, const void* d_kcache, const void* d_
  * attention over the cache (4 query heads per KV head served from one pass over K/V) and the merge of the
  * nsplit context slices, in ONE launch.  d_qkv bf16 [B,(Hq+2Hkv)*D] (un-rotated projection of the new token);
  * d_pos / d_slot int32 [B] (position id, cache slot = tokens already cached); d_ticket uint32 [B*Hkv], zeroed
- * once by the caller; d_workspace fp32 [B*Hkv*nsplit*4*(D+2)].  Same result as vz_op_rope_kv followed by
+ * once by the caller; d_workspace fp32 [B*Hkv*nsplit*(4*D+32)].  Same result as vz_op_rope_kv followed by
  * vz_op_attention_decode. */
 int vz_op_attention_decode_fused(const void* d_qkv, void* d_kcache, void* d_vcache, void* d_o, float* d_workspace,
                                  unsigned* d_ticket, const float* d_cos, const float* d_sin, const int* d_pos,

@@ -363,3 +363,25 @@ def test_gemm256_identity_asymmetric(B):
     w = (torch.arange(384 * K, device="cuda").view(384, K) % 251 - 125).float().bfloat16()
     out = B.linear(x, w, out_fp32=True, impl=2)
     assert torch.equal(out, w.float().t().contiguous())
+
+
+@pytest.mark.parametrize("case", [c for c in ATTN_CASES if c[6] in (64, 128)], ids=[c[0] for c in ATTN_CASES if c[6] in (64, 128)])
+def test_attention_v2_matches_v1(B, case):
+    """v2 (32 rows per wave, double-buffered, hardware-transposed V reads, exp2-based softmax, mask-free fast path) against
+    v1 (transposed LDS writes, expf): same tile order and MFMA order, so only the exponential's last bits differ."""
+    name, Bn, Sq, Sk, Hq, Hkv, D, causal, q_pos0, window, ragged = case
+    q = _rand((Bn, Sq, Hq, D), 1.0, 70).bfloat16()
+    k = _rand((Bn, Sk, Hkv, D), 1.0, 71).bfloat16()
+    v = _rand((Bn, Sk, Hkv, D), 1.0, 72).bfloat16()
+    kv_len = torch.tensor([Sk, Sk // 2 + 3][:Bn], dtype=torch.int32, device="cuda") if ragged else None
+    try:
+        B.check(B.lib().vz_tune_set(2, 1))
+        o1 = B.attention(q, k, v, D ** -0.5, causal, q_pos0, window, kv_len)
+    finally:
+        B.check(B.lib().vz_tune_set(2, 2))
+    o2 = B.attention(q, k, v, D ** -0.5, causal, q_pos0, window, kv_len)
+    if ragged:
+        for b in range(Bn):
+            o1[b, int(kv_len[b]):] = 0
+            o2[b, int(kv_len[b]):] = 0
+    check_close(f"attention v2 vs v1 {name}", o2, o1.float(), 8e-3, 5e-4)

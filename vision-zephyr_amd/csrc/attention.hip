@@ -188,6 +188,268 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(FlashParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2 (head_dim 64 / 128): 4 waves x 32 query rows = 128 rows per workgroup, 64-key tiles.
+//   * every K fragment read from LDS feeds two query tiles (halves the LDS bytes per MFMA of v1);
+//   * V is staged ROW-major like K (plain 16-byte LDS writes) and consumed through the hardware transposing
+//     read ds_read_b64_tr_b16: for the V^T A-operand of O^T += V^T P^T lane (g = lane>>4, c = lane&15) needs
+//     V[key = tile*16 + 4g + r][d = d0 + c], r = 0..3, which is exactly what one tr-read returns when lane
+//     4q+p of a 16-lane group supplies &V[block row q][d0 + 4p]; row stride 2*HD+32 B makes the 32-lane
+//     halves conflict-free;
+//   * K/V tiles are double-buffered with the split register staging (global loads for tile t+1 issued before
+//     the MFMAs of tile t, LDS writes after them, one barrier per tile).
+// Arithmetic, masking and rounding are identical to flash_attn_kernel (same tile order, same MFMA order).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+// Online-softmax step of one 16-query tile.  FULL = every key of the tile is visible to every query of the wave
+// (no padding, not on the causal diagonal, inside the window): the mask arithmetic is skipped - wave-uniform choice,
+// identical values.  exp(x) is evaluated as exp2(x * log2e) on pre-scaled scores: one FMA + v_exp_f32 per element.
+template <int NT, int DT, bool FULL>
+__device__ __forceinline__ void softmax_tile(f32x4 (&sacc)[NT], float& m_run, float& l_run, f32x4 (&oacc)[DT], bf16x8 (&pf)[NT / 2],
+                                             int key0, int g, int kv_len, int causal, int qpos, int window, float scale_log2) {
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sv = sacc[nt][r] * scale_log2;
+            if (!FULL) {
+                const int kidx = key0 + nt * 16 + 4 * g + r;
+                bool ok = kidx < kv_len;
+                if (causal) ok = ok && kidx <= qpos && (window <= 0 || kidx > qpos - window);
+                sv = ok ? sv : -INFINITY;
+            }
+            sacc[nt][r] = sv;
+            m_tile = fmaxf(m_tile, sv);
+        }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    const float m_new = fmaxf(m_run, m_tile);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+    float psum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(sacc[nt][r] - m_safe);
+            sacc[nt][r] = e;
+            psum += e;
+        }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (!__all(alpha == 1.0f)) {      // the running maximum did not move for any query of the wave: nothing to rescale
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha;
+        }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NT / 2; ++s2) {
+        bf16x8 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t[r] = (__bf16)sacc[2 * s2][r];
+            t[4 + r] = (__bf16)sacc[2 * s2 + 1][r];
+        }
+        pf[s2] = t;
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
+    constexpr int KT = 64;
+    constexpr int KS = HD * 2 + 16;          // K row stride in LDS (bytes)
+    constexpr int VS = HD * 2 + 32;          // V row stride: (VS/4) % 64 == 8 or 40 -> conflict-free tr-reads
+    constexpr int BUF = KT * (KS + VS);
+    constexpr int NT = KT / 16, DS = HD / 32, DT = HD / 16, CPK = HD / 8;
+    constexpr int NLD = (KT * CPK) / 256;    // 16-byte chunks per thread per operand tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    // Causal work grows with the query block index.  Workgroups n and n + 256 tend to share a CU, and 256 is a multiple
+    // of the block count per head, so every other residency round walks the query blocks backwards: a CU then pairs a
+    // long block with a short one (speed only; any placement computes the same values).
+    int qb = blockIdx.x;
+    if (p.causal && (((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8) & 1)) qb = gridDim.x - 1 - qb;
+    const int q0 = qb * 128;
+    const int hk = h / (p.Hq / p.Hkv);
+    const int kv_len = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+
+    bf16x8 qf0[DS], qf1[DS];
+    int qrow0 = q0 + wave * 32 + c, qrow1 = qrow0 + 16;
+    const bool q_valid0 = qrow0 < p.Sq, q_valid1 = qrow1 < p.Sq;
+    if (!q_valid0) qrow0 = p.Sq - 1;
+    if (!q_valid1) qrow1 = p.Sq - 1;
+    const int qpos0 = p.q_pos0 + qrow0, qpos1 = p.q_pos0 + qrow1;
+    {
+        const bf16_t* qp0 = p.q + (size_t)b * p.q_bs + (size_t)qrow0 * p.q_ss + (size_t)h * p.q_hs;
+        const bf16_t* qp1 = p.q + (size_t)b * p.q_bs + (size_t)qrow1 * p.q_ss + (size_t)h * p.q_hs;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) {
+            qf0[ds] = *(const bf16x8*)(qp0 + ds * 32 + g * 8);
+            qf1[ds] = *(const bf16x8*)(qp1 + ds * 32 + g * 8);
+        }
+    }
+    f32x4 oacc0[DT], oacc1[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { oacc0[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; oacc1[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    float m_run0 = -INFINITY, m_run1 = -INFINITY, l_run0 = 0.f, l_run1 = 0.f;
+
+    int k_end = kv_len, k_begin = 0;
+    if (p.causal) {
+        const int last_q = min(q0 + 127, p.Sq - 1) + p.q_pos0;
+        k_end = min(k_end, last_q + 1);
+        if (p.window > 0) k_begin = max(0, q0 + p.q_pos0 - p.window + 1);
+    }
+    const int t_begin = k_begin / KT, t_end = (k_end + KT - 1) / KT;
+    const bf16_t* kbase = p.k + (size_t)b * p.k_bs + (size_t)hk * p.k_hs;
+    const bf16_t* vbase = p.v + (size_t)b * p.v_bs + (size_t)hk * p.v_hs;
+    const int last_key = kv_len > 0 ? kv_len - 1 : 0;
+
+    // split register staging (macros, not lambdas: arrays captured by reference end up in scratch)
+    typedef __attribute__((ext_vector_type(4))) unsigned stg_t;
+    stg_t kst[NLD], vst[NLD];
+#define VZ_G_LOAD(T)                                                                           \
+    {                                                                                          \
+        const int key0_ = (T) * KT;                                                            \
+        _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                      \
+            const int ch = i * 256 + tid;                                                      \
+            const int kr = ch / CPK, dc = ch % CPK;                                            \
+            const int krow = min(key0_ + kr, last_key);                                        \
+            kst[i] = *(const stg_t*)(kbase + (size_t)krow * p.k_ss + dc * 8);                  \
+            vst[i] = *(const stg_t*)(vbase + (size_t)krow * p.v_ss + dc * 8);                  \
+        }                                                                                      \
+    }
+#define VZ_L_STORE(BUFI)                                                                       \
+    {                                                                                          \
+        char* Ks_ = smem + (BUFI) * BUF;                                                       \
+        char* Vs_ = Ks_ + KT * KS;                                                             \
+        _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                      \
+            const int ch = i * 256 + tid;                                                      \
+            const int kr = ch / CPK, dc = ch % CPK;                                            \
+            *(stg_t*)(Ks_ + kr * KS + dc * 16) = kst[i];                                       \
+            *(stg_t*)(Vs_ + kr * VS + dc * 16) = vst[i];                                       \
+        }                                                                                      \
+    }
+    if (t_begin < t_end) { VZ_G_LOAD(t_begin) VZ_L_STORE(0) }
+    // The Q fragments came from global loads.  hipcc's waitcnt pass joins the loop's paths conservatively and would
+    // otherwise wait for "the loads that may still be writing qf" right after each tile's prefetch is issued, i.e.
+    // drain the prefetch every iteration.  Passing the fragments through an empty asm makes their producer opaque
+    // (one real wait here, none in the loop).
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) {
+        asm volatile("" : "+v"(qf0[ds]));
+        asm volatile("" : "+v"(qf1[ds]));
+    }
+    __syncthreads();
+    // tr-read address of this lane inside a [16 keys][16 d] block: row q4 = (lane&15)>>2 of lane group g, columns 4p
+    const int tr_off = (4 * g + (c >> 2)) * VS + (c & 3) * 8;
+    const float scale_log2 = p.scale * 1.4426950408889634f;
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int key0 = t * KT;
+        if (t + 1 < t_end) VZ_G_LOAD(t + 1)
+        const char* Ks = smem + cur * BUF;
+        const char* Vs = Ks + KT * KS;
+        // ---- S^T = K Q^T: sacc[qt][nt][r] = S[key0 + nt*16 + 4g + r][query c of tile qt] ----
+        f32x4 sacc0[NT], sacc1[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            // all DS fragment reads of this key tile are issued before the first MFMA that needs one (their LDS
+            // latency overlaps instead of being paid once per MFMA pair)
+            bf16x8 kf[DS];
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) kf[ds] = *(const bf16x8*)(Ks + (nt * 16 + c) * KS + ds * 64 + g * 16);
+            sacc0[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            sacc1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) {
+                sacc0[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ds], qf0[ds], sacc0[nt], 0, 0, 0);
+                sacc1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ds], qf1[ds], sacc1[nt], 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax per query (lane column) ----
+        bf16x8 pf0[NT / 2], pf1[NT / 2];
+        // the tile is fully visible to this wave's 32 queries when it lies below the causal diagonal of the wave's first
+        // row, inside every row's window and inside the valid keys (wave-uniform)
+        const int w_first = p.q_pos0 + q0 + wave * 32, w_last = w_first + 31;
+        const bool full = key0 + KT <= kv_len && (!p.causal || (key0 + KT - 1 <= w_first && (p.window <= 0 || key0 > w_last - p.window)));
+        if (full) {
+            softmax_tile<NT, DT, true>(sacc0, m_run0, l_run0, oacc0, pf0, key0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
+            softmax_tile<NT, DT, true>(sacc1, m_run1, l_run1, oacc1, pf1, key0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
+        } else {
+            softmax_tile<NT, DT, false>(sacc0, m_run0, l_run0, oacc0, pf0, key0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
+            softmax_tile<NT, DT, false>(sacc1, m_run1, l_run1, oacc1, pf1, key0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
+        }
+        // ---- O^T += V^T P^T: the V^T fragment (two transposing reads) feeds both query tiles ----
+#pragma unroll
+        for (int s2 = 0; s2 < NT / 2; ++s2)
+#pragma unroll
+            for (int d4 = 0; d4 < DT; d4 += 4) {
+                bf16x8 vf[4];      // four V^T fragments (8 transposing reads) in flight before their MFMAs
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const char* vp = Vs + tr_off + (d4 + u) * 32;
+                    const bf16x4 v0 = lds_tr16(vp + (2 * s2) * 16 * VS);
+                    const bf16x4 v1 = lds_tr16(vp + (2 * s2 + 1) * 16 * VS);
+                    vf[u] = (bf16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    oacc0[d4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], pf0[s2], oacc0[d4 + u], 0, 0, 0);
+                    oacc1[d4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], pf1[s2], oacc1[d4 + u], 0, 0, 0);
+                }
+            }
+        if (t + 1 < t_end) VZ_L_STORE(cur ^ 1)
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef VZ_G_LOAD
+#undef VZ_L_STORE
+    if (q_valid0) {
+        const float inv = l_run0 > 0.f ? 1.0f / l_run0 : 0.f;
+        bf16_t* op = p.o + (size_t)b * p.o_bs + (size_t)qrow0 * p.o_ss + (size_t)h * p.o_hs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            uint2 pk;
+            pk.x = pack_bf16x2(oacc0[dt][0] * inv, oacc0[dt][1] * inv);
+            pk.y = pack_bf16x2(oacc0[dt][2] * inv, oacc0[dt][3] * inv);
+            *(uint2*)(op + dt * 16 + 4 * g) = pk;
+        }
+    }
+    if (q_valid1) {
+        const float inv = l_run1 > 0.f ? 1.0f / l_run1 : 0.f;
+        bf16_t* op = p.o + (size_t)b * p.o_bs + (size_t)qrow1 * p.o_ss + (size_t)h * p.o_hs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            uint2 pk;
+            pk.x = pack_bf16x2(oacc1[dt][0] * inv, oacc1[dt][1] * inv);
+            pk.y = pack_bf16x2(oacc1[dt][2] * inv, oacc1[dt][3] * inv);
+            *(uint2*)(op + dt * 16 + 4 * g) = pk;
+        }
+    }
+}
+
+template <int HD>
+int launch_flash2(const FlashParams& p, hipStream_t s) {
+    constexpr int LDS = 2 * 64 * (HD * 2 + 16 + HD * 2 + 32);
+    { int r = vz_init_attention_kernels(); if (r) return r; }
+    dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
+    hipLaunchKernelGGL((flash_attn2_kernel<HD>), grid, dim3(256), LDS, s, p);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
 template <int HD, int KT>
 int launch_flash(const FlashParams& p, hipStream_t s) {
     constexpr int LDS = KT * (HD * 2 + 16) + HD * (KT * 2 + 8);
@@ -308,10 +570,15 @@ static int set_flash_attr() {
     return VZ_OK;
 }
 
+static int g_attn_version = 2;     // 1 = v1 kernel for every head_dim (tests / A-B), 2 = v2 for head_dim 64 and 128
+void vz_set_attn_version(int v) { g_attn_version = v; }
+
 int vz_init_attention_kernels() {
     static bool done = false;
     if (done) return VZ_OK;
     int r;
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 * 2 + 16 + 64 * 2 + 32)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 2 + 16 + 128 * 2 + 32)));
     if ((r = set_flash_attr<64, 64>())) return r;
     if ((r = set_flash_attr<128, 64>())) return r;
     if ((r = set_flash_attr<512, 32>())) return r;
@@ -334,6 +601,10 @@ int vz_launch_attention(const AttnArgs& a, hipStream_t s) {
     p.q_bs = a.q_bs; p.q_ss = a.q_ss; p.q_hs = a.q_hs; p.k_bs = a.k_bs; p.k_ss = a.k_ss; p.k_hs = a.k_hs;
     p.v_bs = a.v_bs; p.v_ss = a.v_ss; p.v_hs = a.v_hs; p.o_bs = a.o_bs; p.o_ss = a.o_ss; p.o_hs = a.o_hs;
     p.scale = a.scale; p.causal = a.causal; p.q_pos0 = a.q_pos0; p.window = a.window; p.kv_len = a.kv_len;
+    if (g_attn_version != 1) {
+        if (a.head_dim == 64) return launch_flash2<64>(p, s);
+        if (a.head_dim == 128) return launch_flash2<128>(p, s);
+    }
     switch (a.head_dim) {
         case 64: return launch_flash<64, 64>(p, s);
         case 128: return launch_flash<128, 64>(p, s);

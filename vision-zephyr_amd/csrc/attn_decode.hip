@@ -3,23 +3,37 @@
 //   + append of K/V to the cache + softmax(q K^T) V over the cache (hf:...:139-178, GQA, sliding window)
 //   + the combine of the context splits, all in ONE kernel.
 //
-// HBM-bound: per layer and token the kernel streams the KV cache once (2 * 8 * ctx * 256 B = 8.4 MB at
-// ctx 2048).  Grid = (nsplit, Hkv, B): a workgroup owns one KV head and one slice of the context and
-// serves the 4 query heads of that KV head from a single pass over K and V (GQA without repeat_kv, K/V
-// read once instead of 4x).  K/V rows are read with 16-byte loads straight to VGPRs, 16 lanes per
-// 256-byte row, 16 rows in flight per workgroup pass; the tiny per-split partials (m, l, o[4][128]) go
-// through HBM and the LAST workgroup to arrive for a (slot, kv head) merges them
-// (agent-scope release -> ticket -> acquire; placement independent, cdna guide section 6 G16).
-// Every per-step quantity (position, cache slot, visible length) is read from device memory, so one
-// captured hipGraph replays for every token.
+// HBM/latency-bound: per layer and token the kernel streams the KV cache once (2 * 8 * ctx * 256 B = 8.4 MB
+// at ctx 2048) and sits on the critical path of every decoded token, so the design minimises the dependent
+// chain rather than the byte count:
+//   * grid (nsplit, Hkv, B): a workgroup owns one KV head and one slice of the context and serves the 4 query
+//     heads of that KV head from a single pass over K and V (GQA without repeat_kv, K/V read once, not 4x);
+//   * the K and V rows of the slice are requested FIRST (16-byte loads straight to VGPRs, 16 lanes per
+//     256-byte row, up to 8+8 rows per lane in flight); the RoPE of the new token runs under that latency;
+//   * the per-split partials go to HBM with write-through (sc1) stores, one relaxed agent-scope ticket per
+//     workgroup, and the LAST workgroup to arrive for a (slot, kv head) merges them with sc1 loads - no
+//     release/acquire cache maintenance on the critical path (CDNA4 guide section 6 G16, valid form "sc1 payload +
+//     drained ticket, last arriver told by the value its add returned"); placement independent.
+// Every per-step quantity (position, cache slot) is read from device memory, so one captured hipGraph
+// replays for every token.
 #include "vz_common.h"
 
 namespace {
 
-constexpr int D = 128;          // head_dim
-constexpr int G = 4;            // query heads per KV head (32 / 8)
-constexpr int CH = 128;         // keys per inner chunk
-constexpr int PW = G * (D + 2); // floats per partial record: per head [m, l, o[128]]
+constexpr int D = 128;            // head_dim
+constexpr int G = 4;              // query heads per KV head (32 / 8)
+constexpr int CH = 128;           // keys per inner chunk
+constexpr int NR = CH / 16;       // K (and V) rows per lane per chunk
+constexpr int PW = G * D + 32;    // floats per partial record: o[4][128] | m[4] l[4] pad  (17 x 128-byte lines)
+
+typedef unsigned __attribute__((address_space(1))) gu32;
+
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+    return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 
 struct FusedParams {
     const bf16_t* qkv;    // [B, (Hq + 2 Hkv) * D] fresh projection of the new token
@@ -54,13 +68,34 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(FusedParams p) {
     const int k0 = lo + split * per, k1 = min(len, k0 + per);
     const int heads = p.Hq + 2 * p.Hkv;
     const bf16_t* row = p.qkv + (size_t)b * heads * D;
+    bf16_t* kb = p.kc + ((size_t)b * p.Hkv + hk) * (size_t)p.max_ctx * D;
+    bf16_t* vb = p.vc + ((size_t)b * p.Hkv + hk) * (size_t)p.max_ctx * D;
 
-    // ---- RoPE: thread (h = tid>>6, pair = lane) rotates (d, d+64) of query head hk*G + h ----
+    // ---- the first chunk's K and V rows go in flight before anything else (the new token's row, index `slot`,
+    //      is not in the cache yet: it is patched in from LDS after the RoPE) ----
+    uint4 kreg[NR], vreg[NR];
+    auto issue = [&](int c0, int n) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int kk = ks + 16 * i, kidx = c0 + kk;
+            kreg[i] = make_uint4(0, 0, 0, 0);
+            if (kk < n && kidx != slot) kreg[i] = *(const uint4*)(kb + (size_t)kidx * D + sub * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int kk = ks + 16 * i, kidx = c0 + kk;
+            vreg[i] = make_uint4(0, 0, 0, 0);
+            if (kk < n && kidx != slot) vreg[i] = *(const uint4*)(vb + (size_t)kidx * D + sub * 8);
+        }
+    };
+    if (k0 < k1) issue(k0, min(CH, k1 - k0));
+
+    // ---- RoPE: thread (h = wave, pair = lane) rotates (d, d+64) of query head hk*G + h ----
     {
         const float c = p.cosT[(size_t)position * (D / 2) + lane], s = p.sinT[(size_t)position * (D / 2) + lane];
         const bf16_t* qh = row + (size_t)(hk * G + wave) * D;
         const float x = bf16_to_f32(qh[lane]), y = bf16_to_f32(qh[lane + 64]);
-        // round to bf16 exactly like the separate RoPE kernel does before the attention consumes it
+        // rounded to bf16 exactly like the stand-alone RoPE kernel before the attention consumes it
         q_s[wave][lane] = bf16_to_f32(f32_to_bf16(x * c - y * s)) * p.scale;
         q_s[wave][lane + 64] = bf16_to_f32(f32_to_bf16(y * c + x * s)) * p.scale;
         if (wave == 0) {
@@ -76,8 +111,6 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(FusedParams p) {
     }
     if (tid < G) { stat[G + tid] = -INFINITY; stat[2 * G + tid] = 0.f; }
     __syncthreads();
-    bf16_t* kb = p.kc + ((size_t)b * p.Hkv + hk) * (size_t)p.max_ctx * D;
-    bf16_t* vb = p.vc + ((size_t)b * p.Hkv + hk) * (size_t)p.max_ctx * D;
     if (split == 0 && tid < 32) {   // one workgroup per (slot, kv head) appends the new row to the cache
         if (tid < 16) *(uint4*)(kb + (size_t)slot * D + tid * 8) = *(const uint4*)(knew + tid * 8);
         else *(uint4*)(vb + (size_t)slot * D + (tid - 16) * 8) = *(const uint4*)(vnew + (tid - 16) * 8);
@@ -96,24 +129,16 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(FusedParams p) {
 
     for (int c0 = k0; c0 < k1; c0 += CH) {
         const int n = min(CH, k1 - c0);
-        // ---- every K and V row of the chunk goes in flight first (8 + 8 x 16 B per lane): the scores and the
-        //      softmax run under the V loads' latency ----
-        uint4 kreg[CH / 16], vreg[CH / 16];
+        if (c0 != k0) issue(c0, n);
+        if (slot >= c0 && slot < c0 + n && ((slot - c0) & 15) == ks) {   // this lane group holds the new token's row
+            const int i_new = (slot - c0) >> 4;
 #pragma unroll
-        for (int i = 0; i < CH / 16; ++i) {
-            const int kk = ks + 16 * i, kidx = c0 + kk;
-            kreg[i] = make_uint4(0, 0, 0, 0);
-            if (kk < n) kreg[i] = kidx == slot ? *(const uint4*)(knew + sub * 8) : *(const uint4*)(kb + (size_t)kidx * D + sub * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < CH / 16; ++i) {
-            const int kk = ks + 16 * i, kidx = c0 + kk;
-            vreg[i] = make_uint4(0, 0, 0, 0);
-            if (kk < n) vreg[i] = kidx == slot ? *(const uint4*)(vnew + sub * 8) : *(const uint4*)(vb + (size_t)kidx * D + sub * 8);
+            for (int i = 0; i < NR; ++i)
+                if (i == i_new) { kreg[i] = *(const uint4*)(knew + sub * 8); vreg[i] = *(const uint4*)(vnew + sub * 8); }
         }
         // ---- scores ----
 #pragma unroll
-        for (int i = 0; i < CH / 16; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int kk = ks + 16 * i;
             const u16x8 kv = __builtin_bit_cast(u16x8, kreg[i]);
             float s[G] = {0.f, 0.f, 0.f, 0.f};
@@ -157,7 +182,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(FusedParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[h][j] *= al[h];
 #pragma unroll
-        for (int i = 0; i < CH / 16; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int kk = ks + 16 * i;
             if (kk < n) {
                 const u16x8 vv = __builtin_bit_cast(u16x8, vreg[i]);
@@ -174,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(FusedParams p) {
         }
         __syncthreads();   // sc / stat are rewritten by the next chunk
     }
-    // ---- reduce the 16 key slots through LDS, write this split's partial ----
+    // ---- reduce the 16 key slots through LDS, write this split's partial (write-through stores) ----
 #pragma unroll
     for (int h = 0; h < G; ++h) {
         *(f32x4*)&red[ks][h][sub * 8] = (f32x4){acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
@@ -187,33 +212,25 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(FusedParams p) {
         float v = 0.f;
 #pragma unroll
         for (int s16 = 0; s16 < 16; ++s16) v += red[s16][h][d];
-        po[h * (D + 2) + 2 + d] = v;
+        st_sc1(po + i, v);
     }
-    if (tid < G) { po[tid * (D + 2)] = stat[G + tid]; po[tid * (D + 2) + 1] = stat[2 * G + tid]; }
+    if (tid < G) { st_sc1(po + G * D + tid, stat[G + tid]); st_sc1(po + G * D + G + tid, stat[2 * G + tid]); }
 
-    // ---- publish + ticket; the last arriver for (b, hk) merges all splits ----
+    // ---- every storing wave drains its stores, then ONE lane takes the ticket; the last arriver merges ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = __hip_atomic_fetch_add(p.ticket + (size_t)b * p.Hkv + hk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = (t == (unsigned)p.nsplit - 1) ? 1u : 0u;
-        if (last_flag) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
     }
-    __syncthreads();
+    __syncthreads();   // the wave that added joins this barrier after its add returned; everyone loads behind it
     if (!last_flag) return;
-    // ---- merge: weights w[h][s] = exp(m_s - m) in LDS first, then every thread sums its (h, d) over the splits
-    //      with the loads of all splits independent (8 in flight) ----
     const float* pp = p.part + ((size_t)b * p.Hkv + hk) * p.nsplit * PW;
     float* wgt = &red[0][0][0];            // [G][64] weights, then [G] 1/l   (red is free again)
-    if (tid < G * 64) {
+    {
         const int h = tid >> 6, s2 = tid & 63;
         float ms = -INFINITY, ls = 0.f;
-        if (s2 < p.nsplit) { ms = pp[(size_t)s2 * PW + h * (D + 2)]; ls = pp[(size_t)s2 * PW + h * (D + 2) + 1]; }
+        if (s2 < p.nsplit) { ms = ld_sc1(pp + (size_t)s2 * PW + G * D + h); ls = ld_sc1(pp + (size_t)s2 * PW + G * D + G + h); }
         const float m = wave_max(ms);
         const float w = ms == -INFINITY ? 0.f : __expf(ms - m);
         const float l = wave_sum(w * ls);
@@ -222,11 +239,11 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(FusedParams p) {
     }
     __syncthreads();
     for (int i = tid; i < G * D; i += 256) {
-        const int h = i >> 7, d = i & 127;
+        const int h = i >> 7;
         float a = 0.f;
 #pragma unroll 8
-        for (int s2 = 0; s2 < p.nsplit; ++s2) a += wgt[h * 64 + s2] * pp[(size_t)s2 * PW + h * (D + 2) + 2 + d];
-        p.o[((size_t)b * p.Hq + hk * G + h) * D + d] = f32_to_bf16(a * wgt[G * 64 + h]);
+        for (int s2 = 0; s2 < p.nsplit; ++s2) a += wgt[h * 64 + s2] * ld_sc1(pp + (size_t)s2 * PW + i);
+        p.o[((size_t)b * p.Hq + hk * G) * D + i] = f32_to_bf16(a * wgt[G * 64 + h]);
     }
     if (tid == 0) __hip_atomic_store(p.ticket + (size_t)b * p.Hkv + hk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

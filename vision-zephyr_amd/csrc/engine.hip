@@ -258,7 +258,7 @@ extern "C" int vz_engine_create(const vz_config* cfg, vz_engine** out) {
     hipError_t er = hipMalloc((void**)&e->kv, e->kv_layer_elems * c.n_layers * sizeof(bf16_t));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_state, (4 * c.max_batch + 4) * sizeof(int));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_logits, (size_t)c.max_batch * c.vocab * sizeof(float));
-    if (er == hipSuccess) er = hipMalloc((void**)&e->d_part, (size_t)c.max_batch * c.n_heads * 64 * (128 + 2) * sizeof(float));
+    if (er == hipSuccess) er = hipMalloc((void**)&e->d_part, (size_t)c.max_batch * c.n_kv_heads * 64 * (4 * 128 + 32) * sizeof(float));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_ticket, 4096);
     if (er == hipSuccess) er = hipMemset(e->d_ticket, 0, 4096);
     if (er != hipSuccess) {
@@ -727,6 +727,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
 extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 0) { vz_set_gemv_variant(value); return VZ_OK; }
     if (knob == 1) { vz_set_gemm_choice(value); return VZ_OK; }
+    if (knob == 2) { vz_set_attn_version(value); return VZ_OK; }
     vz_set_error("tune_set: unknown knob %d", knob);
     return VZ_ERR_ARG;
 }

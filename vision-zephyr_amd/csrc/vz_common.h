@@ -121,6 +121,7 @@ struct AttnArgs {
     const int* kv_len;
 };
 int vz_launch_attention(const AttnArgs& a, hipStream_t s);
+void vz_set_attn_version(int v);
 
 // decode attention: one query token per slot against the KV cache; lengths live on the device
 struct AttnDecodeArgs {
@@ -139,7 +140,7 @@ int vz_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 struct AttnDecodeFusedArgs {
     const bf16_t* qkv;     // [B, (Hq+2Hkv)*D]
     bf16_t *kc, *vc, *o;   // caches for this layer [B][Hkv][max_ctx][D]; o [B,Hq,D]
-    float* part;           // [B*Hkv*nsplit*4*(D+2)]
+    float* part;           // [B*Hkv*nsplit*(4*D+32)]
     unsigned* ticket;      // [B*Hkv], zeroed once
     const float *cosT, *sinT;
     const int *pos, *slot; // device int32 [B]

@@ -215,7 +215,7 @@ def attention_decode_fused(qkv, kcache, vcache, cos, sin, pos, slot, Hq, scale, 
     """qkv bf16 [B,(Hq+2Hkv)*D] -> o [B,Hq,D]; appends the new K/V rows to the caches in place."""
     _need_cuda(qkv, kcache, vcache, cos, sin, pos, slot)
     Bn, Hkv, max_ctx, D = kcache.shape
-    ws = torch.empty(Bn * Hkv * nsplit * 4 * (D + 2), dtype=torch.float32, device=qkv.device)
+    ws = torch.empty(Bn * Hkv * nsplit * (4 * D + 32), dtype=torch.float32, device=qkv.device)
     if ticket is None:
         ticket = torch.zeros(Bn * Hkv, dtype=torch.int32, device=qkv.device)
     o = torch.empty(Bn, Hq, D, dtype=torch.bfloat16, device=qkv.device)
