@@ -60,6 +60,16 @@ def algorithmic_work(cfg, S, n_tiles):
     return decode_weight_bytes, prefill_linear_flops
 
 
+def pmc_traffic():
+    """HBM read bytes per GEMV launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in its own run, x1024 x2
+    per the gfx950 correction); PMC counters cannot be read from inside this process."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_pmc_gemv_fetch.json")) as f:
+            return int(json.load(f)["hbm_read_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg_full, S, n_tiles, n_new):
     """The oracle (CPU port of the reference's fp32 path) on this box's host cores, bounded sample:
     1 CLIP tile, 1 Q-Former tile at the full text length, 1 decoder layer of prefill at S, 8 decode tokens
@@ -186,7 +196,7 @@ def main():
         bytes_per_launch = w_bytes / n_gemv_per_token
         ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "gemv_bf16_kernel<1> (decode weight stream)", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
                 "launches": n_l, "avg_launch_ms": round(avg_ms, 5),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "method": f"HIP events around every GEMV launch of {n_prof} eager decode steps after the timed region"}
