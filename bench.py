@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 
 
-def build_model(n_layers, device, max_ctx):
+def build_model(n_layers, device, max_ctx, tp_size=1, tp_rank=0):
     from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
     hf = VisZephyrConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=n_layers, num_attention_heads=32,
                          num_key_value_heads=8, vocab_size=32000, rms_norm_eps=1e-5, sliding_window=4096,
@@ -47,7 +47,7 @@ def build_model(n_layers, device, max_ctx):
     hf.mm_hidden_size = 5120
     hf.mm_vision_select_layer = "-2,-5,-8,-11,6"
     return VisZephyrForCausalLM.from_synthetic(hf, seed=0, device=device, max_batch=1, max_ctx=max_ctx, max_tiles=5,
-                                               max_text=2048)
+                                               max_text=2048, tp_size=tp_size, tp_rank=tp_rank)
 
 
 def algorithmic_work(cfg, S, n_tiles):
@@ -141,7 +141,11 @@ def main():
     from vz_hip import binding as B, synth
     n_tiles, n_ids, n_new = 5, 1889, args.new_tokens
     S = (n_ids - 1) + 32 * n_tiles
-    model = build_model(args.layers, device, max_ctx=S + n_new + 16)
+    # N > 1: replicas by default (one request per GPU, weak scaling).  VZ_BENCH_PARALLELISM=tp runs ONE request over a
+    # tensor-parallel engine instead (Zephyr sharded over the N GPUs, RCCL all-reduce / all-gather; strong scaling).
+    tp_mode = world > 1 and os.environ.get("VZ_BENCH_PARALLELISM", "replicas") == "tp"
+    model = build_model(args.layers, device, max_ctx=S + n_new + 16, tp_size=world if tp_mode else 1,
+                        tp_rank=rank if tp_mode else 0)
     eng, cfg = model.engine, model.arch
     tiles = synth.synth_tiles(n_tiles, seed=1).to(device, torch.bfloat16)
     ids = synth.synth_ids(n_ids, cfg.vocab, image_pos=5, seed=2).unsqueeze(0).to(device)
@@ -211,6 +215,33 @@ def main():
                         "traffic": None, "launches": n_l, "total_ms": round(ms, 3),
                         "algorithmic_flops": pre_flops}
 
+    # ---- N > 1: a guarded tensor-parallel leg beside the replica measurement.  Every rank starts a CHILD process that
+    # runs this script in tp mode (its own rendezvous port), so a failure or hang inside the collectives cannot take the
+    # replica numbers down with it; rank 0 attaches the child's result (or the reason it is missing). ----
+    tp_leg = None
+    if world > 1 and not tp_mode and os.environ.get("VZ_BENCH_TP_LEG", "1") != "0":
+        import subprocess
+        barrier()
+        env = dict(os.environ)
+        env["VZ_BENCH_PARALLELISM"] = "tp"
+        env["VZ_BENCH_TP_LEG"] = "0"
+        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 23)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(min(args.steps, 2)), "--warmup", "1",
+               "--layers", str(args.layers), "--new-tokens", str(args.new_tokens), "--no-cpu-baseline"]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+            if rank == 0:
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode == 0 and lines:
+                    c = json.loads(lines[-1])
+                    tp_leg = {k: c[k] for k in ("value", "unit", "image_to_first_token_ms", "ms_per_step", "scaling")}
+                    tp_leg["parallelism"] = c["config"]["parallelism"]
+                else:
+                    tp_leg = {"value": None, "error": f"child rc={r.returncode}: {(r.stderr or '')[-400:]}"}
+        except subprocess.TimeoutExpired:
+            if rank == 0:
+                tp_leg = {"value": None, "error": "tensor-parallel child timed out after 420 s"}
+        barrier()
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -222,7 +253,7 @@ def main():
         except Exception as ex:   # the GPU numbers stand on their own; say why the CPU leg is missing
             cpu = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                    "sample": f"failed: {type(ex).__name__}: {ex}"}
-    n_dec_tokens = (n_new - 1) * args.steps * world
+    n_dec_tokens = (n_new - 1) * args.steps * (1 if tp_mode else world)
     line = {
         "metric": "decode tokens/sec (image->first-token ms alongside), Zephyr-7B anyres 5-tile",
         "value": round(n_dec_tokens / dec_sum, 2) if world == 1 else round(n_dec_tokens / dec_sum, 2),
@@ -230,14 +261,17 @@ def main():
         "image_to_first_token_ms": round(ttft_sum / args.steps * 1e3, 2),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if tp_mode else "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (hash-generated weights seed 0, N(0,1) tiles, uniform ids)",
         "config": {"workload": f"configs[2]: 5 anyres tiles (4 crops + 1 global) + {n_ids}-id prompt -> S={S}, "
                                f"{n_new} greedy new tokens, batch 1 per GPU",
                    "layers": cfg.n_layers, "seq_len": S, "new_tokens": n_new,
-                   "parallelism": "single GPU" if world == 1 else f"dp{world} replicas (one request per GPU, no collective)"},
+                   "parallelism": "single GPU" if world == 1 else (f"tp{world} (one request, Zephyr tensor-parallel over RCCL)" if tp_mode
+                                                                          else f"dp{world} replicas (one request per GPU, no collective)")},
         "roofline": roof, "roofline_prefill": roof_prefill, "cpu_baseline": cpu,
     }
+    if tp_leg is not None:
+        line["tensor_parallel"] = tp_leg
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -146,6 +146,14 @@ int vz_engine_destroy(vz_engine* e);
 int vz_engine_set_weight(vz_engine* e, const char* name, const void* d_ptr, int dtype, long n_elems);
 /* check that every weight the configuration needs has been registered */
 int vz_engine_finalize(vz_engine* e);
+/* Tensor parallelism (vz_config.tp_size > 1): one process per GPU; q/k/v/gate/up column-parallel,
+ * o/down row-parallel with an RCCL all-reduce of [B,S,hidden] bf16 after each (2 per layer), lm_head vocab-parallel with
+ * an all-gather of the fp32 logits; the KV cache is sharded by KV head.  CLIP / Q-Former weights are replicated.
+ * vz_comm_unique_id fills a 128-byte ncclUniqueId on one rank; the caller ships it to the other ranks (any transport) and
+ * every rank calls vz_comm_init with it before its first prefill. */
+int vz_comm_unique_id(char* out128);
+int vz_comm_init(vz_engine* e, const char* id128);
+
 /* fp32 rotary tables [max_pos, head_dim/2] (rotate-half convention, hf:...modeling_mistral.py:51-81,262-317) */
 int vz_engine_set_rope(vz_engine* e, const float* d_cos, const float* d_sin, int max_pos);
 

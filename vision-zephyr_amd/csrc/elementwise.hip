@@ -262,6 +262,16 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 
 __global__ void step_advance_kernel(int* step) { *step += 1; }
 
+// vocab-parallel logits after the all-gather: gathered[r][row][j] (j < Vp, zero-padded shards) -> out[row][r*Vp + j]
+__global__ __launch_bounds__(256) void repack_logits_kernel(const float* __restrict__ g, float* __restrict__ out, int rows, int Vp, int V, int tp) {
+    const long total = (long)rows * V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int row = (int)(i / V), v = (int)(i % V);
+        const int r = v / Vp, j = v - r * Vp;
+        out[i] = g[((size_t)r * rows + row) * Vp + j];
+    }
+}
+
 }  // namespace
 
 static inline int rows_grid(long rows) { return (int)((rows + 3) / 4); }
@@ -354,6 +364,14 @@ int vz_launch_argmax(const float* logits, int rows, int cols, int* ids, int* pos
 
 int vz_launch_step_advance(int* step, hipStream_t s) {
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, step);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
+int vz_launch_repack_logits(const float* gathered, float* out, int rows, int Vp, int V, int tp, hipStream_t s) {
+    long blocks = ((long)rows * V + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(repack_logits_kernel, dim3((int)blocks), dim3(256), 0, s, gathered, out, rows, Vp, V, tp);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }

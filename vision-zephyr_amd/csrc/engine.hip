@@ -21,6 +21,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "vz_common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -122,6 +124,12 @@ enum { K_GEMM = 0, K_GEMV = 1, K_ATTN = 2, K_ATTN_DEC = 3, K_NORM = 4, K_OTHER =
 
 struct vz_engine {
     vz_config c;
+    // tensor parallelism: this rank's share of the 32 query heads / 8 KV heads / 14336 MLP columns and
+    // of the vocabulary (Vp = ceil(vocab / tp) rows of lm_head, zero padded); tp == 1: everything.
+    int tp = 1, rank = 0, Hq_l = 0, Hkv_l = 0, I_l = 0, Vp = 0;
+    ncclComm_t comm = nullptr;
+    float* d_gather = nullptr;     // [tp][rows][Vp] all-gathered logits before the repack
+    size_t gather_floats = 0;
     std::unordered_map<std::string, Weight> w;
     bool finalized = false;
     // rope
@@ -250,15 +258,21 @@ extern "C" int vz_engine_create(const vz_config* cfg, vz_engine** out) {
                  "engine_create: unsupported Q-Former geometry");
     VZ_CHECK_ARG(c.clip_layers + 1 >= c.fusion_groups * c.fusion_layers_per_group + 1, "engine_create: CLIP too shallow for the fusion");
     VZ_CHECK_ARG(c.max_batch >= 1 && c.max_ctx >= 64 && c.max_tiles >= 1 && c.max_text >= 0, "engine_create: bad capacity");
-    VZ_CHECK_ARG(c.tp_size == 1 && c.tp_rank == 0, "engine_create: tensor parallel engine not built in this version");
+    VZ_CHECK_ARG(c.tp_size >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_size, "engine_create: bad tp_size/tp_rank %d/%d", c.tp_size, c.tp_rank);
+    VZ_CHECK_ARG(c.n_kv_heads % c.tp_size == 0 && c.n_heads % c.tp_size == 0 && (c.inter / c.tp_size) % 512 == 0 && c.inter % c.tp_size == 0,
+                 "engine_create: tp_size %d must divide the KV heads (%d) and leave MLP shards that are multiples of 512", c.tp_size, c.n_kv_heads);
+    VZ_CHECK_ARG((c.n_heads / c.tp_size) == 4 * (c.n_kv_heads / c.tp_size), "engine_create: 4 query heads per KV head expected");
     { int r = vz_init_gemm_kernels(); if (r) return r; r = vz_init_attention_kernels(); if (r) return r; }
     vz_engine* e = new vz_engine();
     e->c = c;
-    e->kv_layer_elems = (size_t)2 * c.max_batch * c.n_kv_heads * c.max_ctx * c.head_dim;
+    e->tp = c.tp_size; e->rank = c.tp_rank;
+    e->Hq_l = c.n_heads / c.tp_size; e->Hkv_l = c.n_kv_heads / c.tp_size; e->I_l = c.inter / c.tp_size;
+    e->Vp = (c.vocab + c.tp_size - 1) / c.tp_size;
+    e->kv_layer_elems = (size_t)2 * c.max_batch * e->Hkv_l * c.max_ctx * c.head_dim;
     hipError_t er = hipMalloc((void**)&e->kv, e->kv_layer_elems * c.n_layers * sizeof(bf16_t));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_state, (4 * c.max_batch + 4) * sizeof(int));
-    if (er == hipSuccess) er = hipMalloc((void**)&e->d_logits, (size_t)c.max_batch * c.vocab * sizeof(float));
-    if (er == hipSuccess) er = hipMalloc((void**)&e->d_part, (size_t)c.max_batch * c.n_kv_heads * 64 * (4 * 128 + 32) * sizeof(float));
+    if (er == hipSuccess) er = hipMalloc((void**)&e->d_logits, (size_t)c.max_batch * e->Vp * e->tp * sizeof(float));
+    if (er == hipSuccess) er = hipMalloc((void**)&e->d_part, (size_t)c.max_batch * e->Hkv_l * 64 * (4 * 128 + 32) * sizeof(float));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_ticket, 4096);
     if (er == hipSuccess) er = hipMemset(e->d_ticket, 0, 4096);
     if (er != hipSuccess) {
@@ -282,6 +296,8 @@ extern "C" int vz_engine_destroy(vz_engine* e) {
     if (e->d_logits) hipFree(e->d_logits);
     if (e->d_part) hipFree(e->d_part);
     if (e->d_ticket) hipFree(e->d_ticket);
+    if (e->d_gather) (void)hipFree(e->d_gather);
+    if (e->comm) (void)ncclCommDestroy(e->comm);
     if (e->h_pinned) hipHostFree(e->h_pinned);
     delete e;
     return VZ_OK;
@@ -321,12 +337,12 @@ extern "C" int vz_engine_finalize(vz_engine* e) {
         WB(p + "ca_out.w", H * H); WF(p + "ca_out.b", H);
         WB(p + "ffn1.w", 2 * H * H); WF(p + "ffn1.b", 2 * H); WB(p + "ffn2.w", 2 * H * H); WF(p + "ffn2.b", H);
     }
-    const long qkv_n = (long)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
-    WB("llm.embed", (long)c.vocab * H); WF("llm.norm", H); WB("llm.lm_head", (long)c.vocab * H);
+    const long qkv_n = (long)(e->Hq_l + 2 * e->Hkv_l) * c.head_dim;
+    WB("llm.embed", (long)c.vocab * H); WF("llm.norm", H); WB("llm.lm_head", (long)e->Vp * H);
     for (int i = 0; i < c.n_layers && !rc; ++i) {
         const std::string p = "llm." + std::to_string(i) + ".";
-        WF(p + "in_norm", H); WF(p + "post_norm", H); WB(p + "qkv.w", qkv_n * H); WB(p + "o.w", H * H);
-        WB(p + "gu.w", 2L * c.inter * H); WB(p + "down.w", (long)c.inter * H);
+        WF(p + "in_norm", H); WF(p + "post_norm", H); WB(p + "qkv.w", qkv_n * H); WB(p + "o.w", H * (long)e->Hq_l * c.head_dim);
+        WB(p + "gu.w", 2L * e->I_l * H); WB(p + "down.w", (long)e->I_l * H);
     }
     if (rc) return rc;
     e->finalized = true;
@@ -535,6 +551,60 @@ extern "C" int vz_embed_splice(vz_engine* e, const int* d_kind, const int* d_idx
     return vz_launch_gather_rows(d_kind, d_idx, rows, e->c.hidden, table, (const bf16_t*)d_visual, (bf16_t*)d_out, (hipStream_t)stream);
 }
 
+
+// ---- tensor-parallel collectives (RCCL over xGMI); no-ops at tp == 1 ----
+static int tp_allreduce_bf16(vz_engine* e, bf16_t* buf, size_t count, hipStream_t s) {
+    if (e->tp == 1) return VZ_OK;
+    if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
+    ProfScope ps(e, K_OTHER, s);
+    ncclResult_t r = ncclAllReduce(buf, buf, count, ncclBfloat16, ncclSum, e->comm, s);
+    if (r != ncclSuccess) { vz_set_error("ncclAllReduce failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
+    return VZ_OK;
+}
+
+// lm_head over `rows` hidden rows -> fp32 logits [rows, vocab] in `out`.  Vocab-parallel under TP: every rank computes its
+// Vp rows of the table, the shards are all-gathered and repacked to the dense [rows, vocab] layout on every rank.
+static int lm_head_logits(vz_engine* e, const bf16_t* h, int rows, float* out, hipStream_t s, const float* norm_w) {
+    const vz_config& c = e->c;
+    const int H = c.hidden;
+    int rc = VZ_OK;
+    const bf16_t* lm = WB("llm.lm_head", (long)e->Vp * H);
+    if (rc) return rc;
+    if (e->tp == 1) return linear(e, 0, h, H, lm, H, out, c.vocab, rows, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps);
+    const size_t need = (size_t)(e->tp + 1) * rows * e->Vp;
+    if (need > e->gather_floats) {
+        if (e->d_gather) { VZ_CHECK_HIP(hipStreamSynchronize(s)); VZ_CHECK_HIP(hipFree(e->d_gather)); e->d_gather = nullptr; }
+        VZ_CHECK_HIP(hipMalloc((void**)&e->d_gather, need * sizeof(float)));
+        e->gather_floats = need;
+    }
+    float* local = e->d_gather + (size_t)e->tp * rows * e->Vp;
+    RC(linear(e, 0, h, H, lm, H, local, e->Vp, rows, e->Vp, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps));
+    if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
+    ncclResult_t r = ncclAllGather(local, e->d_gather, (size_t)rows * e->Vp, ncclFloat, e->comm, s);
+    if (r != ncclSuccess) { vz_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
+    return vz_launch_repack_logits(e->d_gather, out, rows, e->Vp, c.vocab, e->tp, s);
+}
+
+extern "C" int vz_comm_unique_id(char* out128) {
+    VZ_CHECK_ARG(out128, "comm_unique_id: null buffer");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) { vz_set_error("ncclGetUniqueId failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
+    memcpy(out128, &id, 128);
+    return VZ_OK;
+}
+
+extern "C" int vz_comm_init(vz_engine* e, const char* id128) {
+    VZ_CHECK_ARG(e && id128, "comm_init: null argument");
+    if (e->comm) return VZ_OK;
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclResult_t r = ncclCommInitRank(&e->comm, e->tp, id, e->rank);
+    if (r != ncclSuccess) { e->comm = nullptr; vz_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
+    return VZ_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // a12: Zephyr prefill
 // ------------------------------------------------------------------------------------------------
@@ -550,13 +620,14 @@ extern "C" int vz_llm_prefill(vz_engine* e, const void* d_embeds, int B, int S, 
                  "prefill: B=%d S=%d outside capacity (max_batch %d, max_ctx %d)", B, S, c.max_batch, c.max_ctx);
     VZ_CHECK_ARG(e->cosT && e->rope_max >= c.max_ctx, "prefill: rotary tables not set or shorter than max_ctx");
     for (int b = 0; b < B; ++b) VZ_CHECK_ARG(h_seqlens[b] >= 1 && h_seqlens[b] <= S, "prefill: seqlen[%d]=%d outside [1,%d]", b, h_seqlens[b], S);
-    const int H = c.hidden, D = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads, QKV = (Hq + 2 * Hkv) * D, I = c.inter;
+    const int H = c.hidden, D = c.head_dim, Hq = e->Hq_l, Hkv = e->Hkv_l, QKV = (Hq + 2 * Hkv) * D, I = e->I_l, A = Hq * D;
+    const bool lead = e->rank == 0;   // the row-parallel partial sums carry the residual on one rank only
     const int rows = B * S;
     size_t need;
     {
         Carver m(nullptr, ~(size_t)0);
-        m.take<bf16_t>((size_t)rows * H); m.take<bf16_t>((size_t)rows * H); m.take<bf16_t>((size_t)rows * QKV); m.take<bf16_t>((size_t)rows * H);
-        m.take<bf16_t>((size_t)rows * H); m.take<bf16_t>((size_t)rows * I); m.take<int>(rows + B + 16); m.take<bf16_t>((size_t)B * H * 2);
+        m.take<bf16_t>((size_t)rows * H); m.take<bf16_t>((size_t)rows * H); m.take<bf16_t>((size_t)rows * QKV); m.take<bf16_t>((size_t)rows * A);
+        m.take<bf16_t>((size_t)rows * A); m.take<bf16_t>((size_t)rows * I); m.take<int>(rows + B + 16); m.take<bf16_t>((size_t)B * H * 2);
         need = m.off + 256;
     }
     RC(ensure_arena(e, need));
@@ -564,8 +635,8 @@ extern "C" int vz_llm_prefill(vz_engine* e, const void* d_embeds, int B, int S, 
     bf16_t* x = m.take<bf16_t>((size_t)rows * H);
     bf16_t* y = m.take<bf16_t>((size_t)rows * H);
     bf16_t* qkv = m.take<bf16_t>((size_t)rows * QKV);
-    bf16_t* q = m.take<bf16_t>((size_t)rows * H);
-    bf16_t* att = m.take<bf16_t>((size_t)rows * H);
+    bf16_t* q = m.take<bf16_t>((size_t)rows * A);
+    bf16_t* att = m.take<bf16_t>((size_t)rows * A);
     bf16_t* act = m.take<bf16_t>((size_t)rows * I);
     int* d_ints = m.take<int>(rows + B + 16);   // slot[rows] | seqlens[B]
     bf16_t* ylast = m.take<bf16_t>((size_t)B * H * 2);
@@ -590,25 +661,26 @@ extern "C" int vz_llm_prefill(vz_engine* e, const void* d_embeds, int B, int S, 
             AttnArgs a;
             a.q = q; a.k = kc_of(e, i); a.v = vc_of(e, i); a.o = att;
             a.B = B; a.Sq = S; a.Sk = S; a.Hq = Hq; a.Hkv = Hkv; a.head_dim = D;
-            a.q_bs = (long)S * H; a.q_ss = H; a.q_hs = D;
+            a.q_bs = (long)S * A; a.q_ss = A; a.q_hs = D;
             a.k_bs = a.v_bs = (long)Hkv * c.max_ctx * D; a.k_ss = a.v_ss = D; a.k_hs = a.v_hs = (long)c.max_ctx * D;
-            a.o_bs = (long)S * H; a.o_ss = H; a.o_hs = D;
+            a.o_bs = (long)S * A; a.o_ss = A; a.o_hs = D;
             a.scale = 0.08838834764831845f;  // 128^-0.5
             a.causal = 1; a.q_pos0 = 0; a.window = c.sliding_window; a.kv_len = d_len;
             RC(vz_launch_attention(a, s));
         }
-        RC(linear(e, 0, att, H, WB(p + "o.w", (long)H * H), H, x, H, rows, H, H, nullptr, x, H, VZ_ACT_NONE, 0, s));
+        RC(linear(e, 0, att, A, WB(p + "o.w", (long)H * A), A, x, H, rows, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s));
+        RC(tp_allreduce_bf16(e, x, (size_t)rows * H, s));
         { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(x, H, y, H, WF(p + "post_norm", H), rows, H, c.rms_eps, s)); }
         RC(linear(e, 0, y, H, WB(p + "gu.w", 2L * I * H), H, act, I, rows, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s));
-        RC(linear(e, 0, act, I, WB(p + "down.w", (long)I * H), I, x, H, rows, H, I, nullptr, x, H, VZ_ACT_NONE, 0, s));
+        RC(linear(e, 0, act, I, WB(p + "down.w", (long)I * H), I, x, H, rows, H, I, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s));
+        RC(tp_allreduce_bf16(e, x, (size_t)rows * H, s));
         if (rc) return rc;
     }
-    const bf16_t* lm = WB("llm.lm_head", (long)c.vocab * H);
     const float* fn = WF("llm.norm", H);
     if (rc) return rc;
     if (d_logits_all) {
         { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(x, H, y, H, fn, rows, H, c.rms_eps, s)); }
-        RC(linear(e, 0, y, H, lm, H, d_logits_all, c.vocab, rows, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s));
+        RC(lm_head_logits(e, y, rows, d_logits_all, s, nullptr));
     }
     if (d_logits_last) {
         {
@@ -616,7 +688,7 @@ extern "C" int vz_llm_prefill(vz_engine* e, const void* d_embeds, int B, int S, 
             for (int b = 0; b < B; ++b) RC(vz_launch_copy_rows(x + ((size_t)b * S + h_seqlens[b] - 1) * H, H, ylast + (size_t)b * H, H, 1, H, s));
         }
         { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(ylast, H, ylast + (size_t)B * H, H, fn, B, H, c.rms_eps, s)); }
-        RC(linear(e, 0, ylast + (size_t)B * H, H, lm, H, d_logits_last, c.vocab, B, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s));
+        RC(lm_head_logits(e, ylast + (size_t)B * H, B, d_logits_last, s, nullptr));
     }
     return rc;
 }
@@ -648,12 +720,13 @@ extern "C" int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, 
 static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, float* d_logits_dbg, hipStream_t s) {
     const vz_config& c = e->c;
     const int B = e->dec_B, mb = c.max_batch;
-    const int H = c.hidden, D = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads, QKV = (Hq + 2 * Hkv) * D, I = c.inter;
+    const int H = c.hidden, D = c.head_dim, Hq = e->Hq_l, Hkv = e->Hkv_l, QKV = (Hq + 2 * Hkv) * D, I = e->I_l, A = Hq * D;
+    const bool lead = e->rank == 0;
     int* cur = e->d_state; int* pos = cur + mb; int* slot = pos + mb; int* len = slot + mb; int* step = len + mb;
     Carver m(e->arena, e->arena_bytes);
     bf16_t* x = m.take<bf16_t>((size_t)B * H);
     bf16_t* qkv = m.take<bf16_t>((size_t)B * QKV);
-    bf16_t* att = m.take<bf16_t>((size_t)B * H);
+    bf16_t* att = m.take<bf16_t>((size_t)B * A);
     bf16_t* act = m.take<bf16_t>((size_t)B * I);
     if (!m.ok) { vz_set_error("decode: workspace too small"); return VZ_ERR_STATE; }
     int rc = VZ_OK;
@@ -670,12 +743,14 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
             a.scale = 0.08838834764831845f;
             RC(vz_launch_attn_decode_fused(a, s));
         }
-        RC(linear(e, 0, att, H, WB(p + "o.w", (long)H * H), H, x, H, B, H, H, nullptr, x, H, VZ_ACT_NONE, 0, s));
+        RC(linear(e, 0, att, A, WB(p + "o.w", (long)H * A), A, x, H, B, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s));
+        RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
         RC(linear(e, 0, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps));
-        RC(linear(e, 0, act, I, WB(p + "down.w", (long)I * H), I, x, H, B, H, I, nullptr, x, H, VZ_ACT_NONE, 0, s));
+        RC(linear(e, 0, act, I, WB(p + "down.w", (long)I * H), I, x, H, B, H, I, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s));
+        RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
         if (rc) return rc;
     }
-    RC(linear(e, 0, x, H, WB("llm.lm_head", (long)c.vocab * H), H, e->d_logits, c.vocab, B, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, WF("llm.norm", H), c.rms_eps));
+    RC(lm_head_logits(e, x, B, e->d_logits, s, WF("llm.norm", H)));
     if (rc) return rc;
     if (d_logits_dbg) {
         // debug copy is indexed by the host (eager mode only)
@@ -696,9 +771,9 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     VZ_CHECK_ARG(e->dec_B >= 1, "decode_steps: call vz_llm_decode_begin first");
     VZ_CHECK_ARG(n >= 1 && d_out_ids, "decode_steps: bad argument");
     const int B = e->dec_B;
-    const size_t need = ((size_t)B * (3 * c.hidden + (c.n_heads + 2 * c.n_kv_heads) * c.head_dim + c.inter)) * 2 + 8192;
+    const size_t need = ((size_t)B * (3 * c.hidden + (c.n_heads + 2 * c.n_kv_heads) * c.head_dim + c.inter)) * 2 + 8192;   // upper bound (tp = 1 sizes)
     RC(ensure_arena(e, need));
-    const bool use_graph = !e->prof_on && !d_logits_dbg && getenv("VZ_NO_GRAPH") == nullptr;
+    const bool use_graph = !e->prof_on && !d_logits_dbg && e->tp == 1 && getenv("VZ_NO_GRAPH") == nullptr;   // collectives run eagerly
     int* step = e->d_state + 4 * c.max_batch;
     VZ_CHECK_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
     if (!use_graph) {

@@ -168,3 +168,4 @@ int vz_init_attention_kernels();
 int vz_launch_copy_rows(const bf16_t* src, long src_stride, bf16_t* dst, long dst_stride, int rows, int cols,
                         hipStream_t s);
 int vz_launch_step_advance(int* step, hipStream_t s);
+int vz_launch_repack_logits(const float* gathered, float* out, int rows, int Vp, int V, int tp, hipStream_t s);

@@ -101,12 +101,13 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
     config_class = VisZephyrConfig
 
     def __init__(self, config, device: Union[str, torch.device] = "cuda:0", max_batch: int = 1,
-                 max_ctx: int = 4096, max_tiles: int = 8, max_text: int = 2048, engine: Optional[Engine] = None):
+                 max_ctx: int = 4096, max_tiles: int = 8, max_text: int = 2048, engine: Optional[Engine] = None,
+                 tp_size: int = 1, tp_rank: int = 0):
         self.config = config
         self.arch = arch_from_config(config)
         self.engine = engine if engine is not None else Engine(self.arch, device=device, max_batch=max_batch,
                                                                max_ctx=max_ctx, max_tiles=max_tiles,
-                                                               max_text=max_text)
+                                                               max_text=max_text, tp_size=tp_size, tp_rank=tp_rank)
         self.device = self.engine.device
         self.dtype = torch.bfloat16
         self.model = VisZephyrModel(config, self)
@@ -119,6 +120,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
     def from_synthetic(cls, config, seed: int = 0, **kw):
         m = cls(config, **kw)
         m.engine.load_synthetic(seed)
+        m.engine.init_comm()
         if m.get_vision_tower() is not None:
             m.get_vision_tower().is_loaded = True
         return m

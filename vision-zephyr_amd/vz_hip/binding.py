@@ -55,6 +55,8 @@ SYMBOLS = {
     "vz_engine_set_weight": (_I, [_P, C.c_char_p, _P, _I, _L]),
     "vz_engine_finalize": (_I, [_P]),
     "vz_engine_set_rope": (_I, [_P, _P, _P, _I]),
+    "vz_comm_unique_id": (_I, [C.c_char_p]),
+    "vz_comm_init": (_I, [_P, C.c_char_p]),
     "vz_clip_fused_features": (_I, [_P, _P, _I, _P, _P, _P]),
     "vz_qformer": (_I, [_P, _P, _I, _P, _I, _I, C.POINTER(C.c_int), _P, _P]),
     "vz_embed_splice": (_I, [_P, _P, _P, _I, _P, _P, _P]),

@@ -20,6 +20,7 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 import torch
 
 from . import binding as B
+from . import tp as TP
 from .synth import ArchConfig, iter_state_dict
 
 _CLIP_PREFIXES = ("model.vision_tower.vision_tower.vision_model.", "model.vision_tower.vision_tower.")
@@ -37,11 +38,14 @@ def rope_tables(cfg: ArchConfig, max_pos: int) -> Tuple[torch.Tensor, torch.Tens
 
 class Engine:
     def __init__(self, cfg: ArchConfig, device="cuda:0", max_batch: int = 1, max_ctx: int = 4096,
-                 max_tiles: int = 8, max_text: int = 2048):
+                 max_tiles: int = 8, max_text: int = 2048, tp_size: int = 1, tp_rank: int = 0):
         self.lib = B.load_library()            # raises when the HIP library is absent: no fallback
         if not torch.cuda.is_available():
             raise RuntimeError("vz_hip.Engine needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.cfg = cfg
+        TP.check_divisible(cfg, tp_size)
+        self.tp_size, self.tp_rank = tp_size, tp_rank
+        self.vp = (cfg.vocab + tp_size - 1) // tp_size          # lm_head rows per rank (zero padded)
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.max_batch, self.max_ctx, self.max_tiles, self.max_text = max_batch, max_ctx, max_tiles, max_text
@@ -53,7 +57,7 @@ class Engine:
             clip_patch=cfg.clip_patch, clip_eps=cfg.clip_eps, qf_queries=cfg.qf_queries, qf_blocks=cfg.qf_blocks,
             qf_heads=cfg.qf_heads, qf_kv_dim=cfg.qf_kv_dim, qf_eps=cfg.qf_eps, fusion_groups=cfg.fusion_groups,
             fusion_layers_per_group=cfg.fusion_layers_per_group, max_batch=max_batch, max_ctx=max_ctx,
-            max_tiles=max_tiles, max_text=max_text, tp_size=1, tp_rank=0)
+            max_tiles=max_tiles, max_text=max_text, tp_size=tp_size, tp_rank=tp_rank)
         h = C.c_void_p()
         B.check(self.lib.vz_engine_create(C.byref(c), C.byref(h)))
         self.h = h
@@ -105,10 +109,12 @@ class Engine:
                 return self._add_clip(name[len(pre):], t)
         if name.startswith(_QF):
             return self._add_qformer(name[len(_QF):], t)
+        t = TP.shard(name, t, self.tp_rank, self.tp_size)       # this rank's slice (identity at tp_size 1 / replicated tensors)
+        I = cfg.inter // self.tp_size
         if name == "model.embed_tokens.weight":
             self._mat("llm.embed", (cfg.vocab, H), t)
         elif name == "lm_head.weight":
-            self._mat("llm.lm_head", (cfg.vocab, H), t)
+            self._mat("llm.lm_head", (self.vp, H), t, slice(0, t.shape[0]))
         elif name == "model.norm.weight":
             self._vec("llm.norm", H, t)
         else:
@@ -117,7 +123,7 @@ class Engine:
                 return False
             i, rest = int(m.group(1)), m.group(2)
             p = f"llm.{i}."
-            qd, kvd = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
+            qd, kvd = cfg.n_heads * cfg.head_dim // self.tp_size, cfg.n_kv_heads * cfg.head_dim // self.tp_size
             if rest == "input_layernorm.weight":
                 self._vec(p + "in_norm", H, t)
             elif rest == "post_attention_layernorm.weight":
@@ -235,6 +241,19 @@ class Engine:
         for name, t in named:
             self.add_weight(name, t)
         self.finalize()
+
+    def init_comm(self):
+        """create the RCCL communicator of a tensor-parallel engine: rank 0's unique id travels over torch.distributed
+        (already initialised by the launcher), then every rank joins."""
+        if self.tp_size == 1:
+            return
+        import torch.distributed as dist
+        buf = C.create_string_buffer(128)
+        if self.tp_rank == 0:
+            B.check(self.lib.vz_comm_unique_id(buf))
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=0)
+        B.check(self.lib.vz_comm_init(self.h, box[0]))
 
     def load_synthetic(self, seed: int = 0):
         """hash-generated weights, produced on the device (bit-identical to the CPU generator)."""
