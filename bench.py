@@ -184,7 +184,7 @@ def main():
 
     # ---- roofline legs: instrumented replays of the same work, HIP events on the launch stream ----
     roof, roof_prefill = None, None
-    if rank == 0:
+    if rank == 0 and not tp_mode:          # (a tensor-parallel engine needs every rank inside each collective)
         w_bytes, pre_flops = algorithmic_work(cfg, S, n_tiles)
         n_gemv_per_token = 4 * cfg.n_layers + 1
         emb = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles])[4]
