@@ -7,22 +7,22 @@
 //   * 8 waves (2 M x 4 N), each owning a 128x64 output tile = 32 accumulators of 16x16 (384 B of LDS
 //     per MFMA), one workgroup per CU, 128 KiB of LDS = 2 K-tile buffers x {A_0, A_1, B_0, B_1};
 //     a half-tile X_h holds the rows every wave needs for its output quadrant h (128 rows x 64 k).
-//   * each K-tile is 4 phases, one output quadrant (16 MFMAs) per phase:
-//        phase 1: read A_0 (8x ds_read_b128) + B_0 (4x)   MFMA quadrant (0,0)   stage A_1(t+1)
-//        phase 2: read B_1 (4x)                           MFMA quadrant (0,1)   stage A_0(t+2)
-//        phase 3: read A_1 (8x)                           MFMA quadrant (1,1)   stage B_0(t+2)
-//        phase 4: (B_0 still in registers)                MFMA quadrant (1,0)   stage B_1(t+2), vmcnt(6)
-//     every phase = {ds_reads, 2 LDS-DMA per thread, s_barrier, lgkmcnt(0), 16 MFMA, s_barrier}.
+//   * each K-tile is 2 phases of 32 MFMAs (two output quadrants each); measured on MI355X the 4-phase form of the
+//     guide spends more time in barrier/LDS latency than in MFMAs with this staging, the 2-phase form is faster:
+//        phase alpha: read A_0 (8x ds_read_b128), B_0, B_1 (4x each)  MFMA quadrants (0,0),(0,1)  stage B_1(t+1), A_1(t+1)
+//        phase beta : read A_1 (8x), B fragments stay in registers    MFMA quadrants (1,0),(1,1)  stage A_0(t+2), B_0(t+2), vmcnt(4)
+//     every phase = {ds_reads, 4 LDS-DMA per thread, lgkmcnt(0), s_barrier, 32 MFMA, s_barrier}; the two wave groups
+//     (upper / lower half of the tile) run one barrier apart, so one group's loads overlap the other's MFMAs.
 //   * operands are staged with 16-byte LDS-DMA (global_load_lds_dwordx4) that stays in flight ACROSS the raw
-//     s_barriers: the only VMEM wait in the loop is one counted `s_waitcnt vmcnt(6)` per K-tile, which
-//     leaves the three newest half-tiles in flight.  Hazards (derivation in DESIGN.md section 4):
-//       RAW  a half-tile of K-tile t+1 is issued no later than phase 1 of tile t, retired by the vmcnt(6) of
-//            phase 4 (6 newer DMAs exist by then), and first read in phase 1 of tile t+1, i.e. after the
-//            barrier that follows the wait;
+//     s_barriers: the only VMEM wait in the loop is one counted `s_waitcnt vmcnt(4)` per K-tile, which
+//     leaves the two newest half-tiles in flight.  Hazards:
+//       RAW  every half-tile of K-tile t+1 is issued no later than phase alpha of tile t, retired by the vmcnt(4) of
+//            phase beta (only the 4 DMAs of that phase are newer), and first read in phase alpha of tile t+1, i.e.
+//            two barriers after the wait (one more than the stagger needs);
 //       WAR  a region is re-staged at the earliest one phase after its last ds_read, and every wave has
 //            passed its lgkmcnt(0) and the phase-end barrier by then.
 //     K-tiles past the end are clamped to the last one (identical bytes re-written), so the loop has no
-//     tail variants and vmcnt(6) is exact in every iteration.
+//     tail variants and vmcnt(4) is exact in every iteration.
 //   * LDS image lane-linear per DMA instruction; XOR swizzle (chunk ^= row & 7) on the SOURCE address and on
 //     the ds_read_b128; XCD-aware bijective tile order; same fused epilogues as gemm.hip.
 #include "vz_common.h"
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
 
     // ---- prologue: K-tile 0 complete, K-tile 1 minus A_1 ----
     stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
-    stage(0, 1); stage(2, 1); stage(3, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    stage(0, 1); stage(2, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -170,15 +170,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
     bf16x8 af[4][2], b0f[2][2], b1f[2][2];   // [mt][ks], [nt][ks]
     for (int t = 0; t < nk; ++t) {
         const char* base = smem + (t & 1) * BUF_BYTES;
-        // ================= phase 1: quadrant (0,0) =================
+        // ================= phase alpha: quadrants (0,0) and (0,1) =================
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b0f[nt][ks] = *(const bf16x8*)(base + 2 * HALF_BYTES + b_rd + nt * 2048 + (koff0 ^ (ks * 64)));
+            for (int ks = 0; ks < 2; ++ks) {
+                b0f[nt][ks] = *(const bf16x8*)(base + 2 * HALF_BYTES + b_rd + nt * 2048 + (koff0 ^ (ks * 64)));
+                b1f[nt][ks] = *(const bf16x8*)(base + 3 * HALF_BYTES + b_rd + nt * 2048 + (koff0 ^ (ks * 64)));
+            }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const bf16x8*)(base + a_rd + mt * 2048 + (koff0 ^ (ks * 64)));
+        stage(3, t + 1);     // B_1, A_1 of the NEXT tile go into the other buffer (last read two / one phase ago)
         stage(1, t + 1);
         PHASE_SYNC_BEGIN()
 #pragma unroll
@@ -186,50 +190,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt) {
                     acc[0][0][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[nt][ks], af[mt][ks], acc[0][0][nt][mt], 0, 0, 0);
-        PHASE_SYNC_END()
-        // ================= phase 2: quadrant (0,1) =================
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b1f[nt][ks] = *(const bf16x8*)(base + 3 * HALF_BYTES + b_rd + nt * 2048 + (koff0 ^ (ks * 64)));
-        stage(0, t + 2);
-        PHASE_SYNC_BEGIN()
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
                     acc[0][1][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[nt][ks], af[mt][ks], acc[0][1][nt][mt], 0, 0, 0);
+                }
         PHASE_SYNC_END()
-        // ================= phase 3: quadrant (1,1) =================
+        // ================= phase beta: quadrants (1,0) and (1,1), B fragments still in registers =================
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const bf16x8*)(base + HALF_BYTES + a_rd + mt * 2048 + (koff0 ^ (ks * 64)));
+        stage(0, t + 2);     // A_0, B_0 of tile t+2 overwrite this tile's copies (read in phase alpha, retired before its barrier)
         stage(2, t + 2);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 DMAs just issued have landed: K-tile t+1 is complete
         PHASE_SYNC_BEGIN()
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[1][1][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[nt][ks], af[mt][ks], acc[1][1][nt][mt], 0, 0, 0);
-        PHASE_SYNC_END()
-        // ================= phase 4: quadrant (1,0), B_0 still in registers =================
-        stage(3, t + 2);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // everything but the 3 newest half-tiles has landed: K-tile t+1 is complete
-        PHASE_SYNC_BEGIN()
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt) {
                     acc[1][0][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[nt][ks], af[mt][ks], acc[1][0][nt][mt], 0, 0, 0);
+                    acc[1][1][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[nt][ks], af[mt][ks], acc[1][1][nt][mt], 0, 0, 0);
+                }
         PHASE_SYNC_END()
     }
     if (!late) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
