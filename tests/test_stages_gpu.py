@@ -302,3 +302,53 @@ def test_decode_graph_equals_eager(env):
     eng.decode_begin(first, [24], [24])
     graph = eng.decode_steps(8)
     assert eager.tolist() == graph.tolist()
+
+
+def test_batched_generate_and_left_padding(env):
+    """true batching (one weight stream for all rows) must give every row exactly what it gets alone, and a left-padded
+    batch (tokenizer_padding_side='left') must score like the same batch right-padded."""
+    cfg, model = env["cfg"], env["model"]
+    S = env["synth"]
+    a = S.synth_ids(21, cfg.vocab, image_pos=-1, seed=21)
+    b = S.synth_ids(14, cfg.vocab, image_pos=-1, seed=22)
+    ids = torch.full((2, 21), 2, dtype=torch.long)
+    ids[0] = a
+    ids[1, :14] = b
+    mask = torch.zeros(2, 21, dtype=torch.long)
+    mask[0] = 1
+    mask[1, :14] = 1
+    both = model.generate(input_ids=ids, attention_mask=mask, do_sample=False, max_new_tokens=5, eos_token_id=None, pad_token_id=2)
+    one_a = model.generate(input_ids=a.unsqueeze(0), do_sample=False, max_new_tokens=5, eos_token_id=None)
+    one_b = model.generate(input_ids=b.unsqueeze(0), do_sample=False, max_new_tokens=5, eos_token_id=None)
+    assert both.shape == (2, 5)
+    assert both[0].tolist() == one_a[0].tolist() and both[1].tolist() == one_b[0].tolist()
+    # eos: row 1 stops at its 2nd token and pads afterwards, row 0 continues
+    stop = int(one_b[0, 1])
+    if stop not in one_a[0].tolist():
+        got = model.generate(input_ids=ids, attention_mask=mask, do_sample=False, max_new_tokens=5, eos_token_id=[stop], pad_token_id=0)
+        assert got[1].tolist()[:2] == one_b[0].tolist()[:2] and set(got[1].tolist()[2:]) <= {0}
+        assert got[0].tolist() == one_a[0].tolist()
+    # left padding: roll row 1 to the right edge
+    ids_l, mask_l = ids.clone(), mask.clone()
+    ids_l[1] = torch.roll(ids[1], 7)
+    mask_l[1] = torch.roll(mask[1], 7)
+    lr = model(input_ids=ids, attention_mask=mask).logits
+    ll = model(input_ids=ids_l, attention_mask=mask_l).logits
+    assert torch.equal(ll[0], lr[0])
+    assert torch.equal(ll[1, 7:], lr[1, :14])
+    gen_l = model.generate(input_ids=ids_l, attention_mask=mask_l, do_sample=False, max_new_tokens=5, eos_token_id=None, pad_token_id=2)
+    assert gen_l.tolist() == both.tolist()
+
+
+def test_sampling_is_seeded_and_follows_the_logits(env):
+    cfg, model = env["cfg"], env["model"]
+    ids = env["synth"].synth_ids(9, cfg.vocab, image_pos=-1, seed=7).unsqueeze(0)
+    g1 = torch.Generator(device=model.device).manual_seed(123)
+    g2 = torch.Generator(device=model.device).manual_seed(123)
+    s1 = model.generate(input_ids=ids, do_sample=True, temperature=0.7, top_p=0.9, max_new_tokens=6, eos_token_id=None, generator=g1)
+    s2 = model.generate(input_ids=ids, do_sample=True, temperature=0.7, top_p=0.9, max_new_tokens=6, eos_token_id=None, generator=g2)
+    assert s1.tolist() == s2.tolist() and s1.shape == (1, 6)
+    # temperature -> 0 collapses onto the greedy path
+    greedy = model.generate(input_ids=ids, do_sample=False, max_new_tokens=4, eos_token_id=None)
+    cold = model.generate(input_ids=ids, do_sample=True, temperature=1e-4, max_new_tokens=4, eos_token_id=None)
+    assert cold.tolist() == greedy.tolist()

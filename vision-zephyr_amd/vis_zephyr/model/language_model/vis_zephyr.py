@@ -167,8 +167,17 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         if inputs_embeds is None:
             inputs_embeds = self.get_model().embed_tokens(input_ids)
         Bsz, S = inputs_embeds.shape[0], inputs_embeds.shape[1]
-        seqlens = self._seqlens(attention_mask, Bsz, S)
-        logits, _ = self.engine.prefill(inputs_embeds, seqlens, position_ids, all_logits=True, last_logits=False)
+        inputs_embeds, rp_mask, position_ids, shifts = self._to_right_padded(inputs_embeds, attention_mask, position_ids)
+        seqlens = self._seqlens(rp_mask, Bsz, S)
+        logits = torch.empty(Bsz, S, self.arch.vocab, dtype=torch.float32, device=self.device)
+        mb = self.engine.max_batch
+        for b0 in range(0, Bsz, mb):        # the engine owns `max_batch` KV slots; larger batches run in chunks
+            sl = slice(b0, min(Bsz, b0 + mb))
+            la, _ = self.engine.prefill(inputs_embeds[sl], seqlens[sl], None if position_ids is None else position_ids[sl],
+                                        all_logits=True, last_logits=False)
+            logits[sl] = la
+        if shifts is not None:              # back to the caller's (left-padded) column order
+            logits = torch.stack([torch.roll(logits[b], shifts[b], 0) for b in range(Bsz)])
         loss = None
         if labels is not None:
             lab = labels.to(logits.device)
@@ -187,8 +196,27 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         lens = m.sum(1).tolist()
         for b in range(Bsz):
             if not bool(m[b, :lens[b]].all()):
-                raise NotImplementedError("only right-padded (prefix) attention masks are built in the MI355X engine")
+                raise NotImplementedError("attention mask is neither right- nor left-padded (holes are not built)")
         return [max(1, int(x)) for x in lens]
+
+    @staticmethod
+    def _to_right_padded(inputs_embeds, attention_mask, position_ids):
+        """The engine's KV cache holds every sequence from slot 0 (right padding).  A left-padded batch
+        (`tokenizer_padding_side = "left"`, ref:vis_zephyr/model/vis_zephyr_arch.py:515-521) is rolled so that each row's
+        real tokens start at column 0; returns the shifts so that per-position outputs can be rolled back."""
+        if attention_mask is None:
+            return inputs_embeds, attention_mask, position_ids, None
+        m = attention_mask.bool()
+        Bsz, S = m.shape
+        lens = m.sum(1)
+        is_left = [bool(lens[b] < S and m[b, S - int(lens[b]):].all() and not m[b, 0]) for b in range(Bsz)]
+        if not any(is_left):
+            return inputs_embeds, attention_mask, position_ids, None
+        shifts = [S - int(lens[b]) if is_left[b] else 0 for b in range(Bsz)]
+        emb = torch.stack([torch.roll(inputs_embeds[b], -shifts[b], 0) for b in range(Bsz)])
+        msk = torch.stack([torch.roll(attention_mask[b], -shifts[b], 0) for b in range(Bsz)])
+        pos = None if position_ids is None else torch.stack([torch.roll(position_ids[b], -shifts[b], 0) for b in range(Bsz)])
+        return emb, msk, pos, shifts
 
     # ---- generate (a3, a13) -------------------------------------------------------------------------
     @torch.no_grad()
@@ -225,9 +253,12 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         if pad_token_id is None:
             pad_token_id = min(eos) if eos else 0
         greedy = (not do_sample) or temperature is None or temperature <= 0
+        inputs_embeds, attention_mask, position_ids, _ = self._to_right_padded(inputs_embeds, attention_mask, position_ids)
         seqlens = self._seqlens(attention_mask, Bsz, S)
+        if Bsz > 1 and greedy and streamer is None and stopping_criteria is None:
+            return self._generate_batched(inputs_embeds, seqlens, position_ids, max_new_tokens, eos, pad_token_id, sync_every)
         outs = []
-        for b in range(Bsz):               # the reference's inference callers are batch 1 (eval_vqa.py:119-120)
+        for b in range(Bsz):               # per-token host callbacks / sampling: one sequence at a time
             outs.append(self._generate_one(inputs_embeds[b:b + 1, :seqlens[b]],
                                            None if position_ids is None else position_ids[b:b + 1, :seqlens[b]],
                                            max_new_tokens, greedy, temperature, top_p, top_k, eos, streamer if Bsz == 1 else None,
@@ -237,6 +268,47 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         for b, o in enumerate(outs):
             res[b, :len(o)] = torch.tensor(o, dtype=torch.long, device=self.device)
         return res
+
+    def _generate_batched(self, embeds, seqlens, position_ids, max_new, eos, pad_token_id, sync_every) -> torch.Tensor:
+        """Greedy decoding of up to `max_batch` (<= 4) sequences at once: one right-padded prefill, then every decode step
+        streams the weights once for all rows (the KV cache, positions and lengths are per slot).  Rows that hit eos keep
+        their slot but emit `pad_token_id` from then on, as HF does."""
+        eng = self.engine
+        Bsz, S = embeds.shape[0], embeds.shape[1]
+        cap = min(eng.max_batch, 4)
+        if Bsz > cap:
+            parts = [self._generate_batched(embeds[i:i + cap], seqlens[i:i + cap],
+                                            None if position_ids is None else position_ids[i:i + cap], max_new, eos,
+                                            pad_token_id, sync_every) for i in range(0, Bsz, cap)]
+            n = max(p.shape[1] for p in parts)
+            out = torch.full((Bsz, n), pad_token_id, dtype=torch.long, device=self.device)
+            r = 0
+            for p in parts:
+                out[r:r + p.shape[0], :p.shape[1]] = p
+                r += p.shape[0]
+            return out
+        if S + max_new > eng.max_ctx:
+            raise ValueError(f"prompt ({S}) + max_new_tokens ({max_new}) exceeds the engine's max_ctx ({eng.max_ctx})")
+        from vz_hip import binding as B
+        _, last = eng.prefill(embeds, seqlens, position_ids, all_logits=False, last_logits=True)
+        first = B.argmax(last)
+        next_pos = [int(seqlens[b]) if position_ids is None else int(position_ids[b, seqlens[b] - 1]) + 1 for b in range(Bsz)]
+        ids = [first.to(torch.long).view(Bsz, 1)]
+        done = torch.tensor([int(t) in eos for t in first.tolist()], dtype=torch.bool)
+        eng.decode_begin(first, next_pos, list(seqlens))
+        remaining = max_new - 1
+        while remaining > 0 and not bool(done.all()):
+            n = min(sync_every, remaining) if eos else remaining
+            chunk = eng.decode_steps(n).to(torch.long).cpu()             # [B, n]
+            remaining -= n
+            for j in range(n):
+                col = chunk[:, j].clone()
+                col[done] = pad_token_id
+                ids.append(col.view(Bsz, 1).to(self.device))
+                done = done | torch.tensor([int(t) in eos for t in chunk[:, j].tolist()]) if eos else done
+                if bool(done.all()):
+                    break
+        return torch.cat([t.to(self.device) for t in ids], dim=1)
 
     def _generate_one(self, embeds, position_ids, max_new, greedy, temperature, top_p, top_k, eos, streamer,
                       stopping_criteria, generator, sync_every, timing=None) -> List[int]:
