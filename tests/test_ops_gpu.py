@@ -368,7 +368,9 @@ def test_gemm256_identity_asymmetric(B):
 @pytest.mark.parametrize("case", [c for c in ATTN_CASES if c[6] in (64, 128)], ids=[c[0] for c in ATTN_CASES if c[6] in (64, 128)])
 def test_attention_v2_matches_v1(B, case):
     """v2 (32 rows per wave, double-buffered, hardware-transposed V reads, exp2-based softmax, mask-free fast path) against
-    v1 (transposed LDS writes, expf): same tile order and MFMA order, so only the exponential's last bits differ."""
+    v1 (transposed LDS writes, expf).  v2 advances the running maximum every 32 keys instead of 64, so the bf16 rounding of
+    the probabilities is taken against a different reference maximum: the two outputs are two independent bf16 roundings
+    of the same attention (each within one bf16 step of the fp64 reference, checked in test_attention)."""
     name, Bn, Sq, Sk, Hq, Hkv, D, causal, q_pos0, window, ragged = case
     q = _rand((Bn, Sq, Hq, D), 1.0, 70).bfloat16()
     k = _rand((Bn, Sk, Hkv, D), 1.0, 71).bfloat16()
@@ -384,4 +386,4 @@ def test_attention_v2_matches_v1(B, case):
         for b in range(Bn):
             o1[b, int(kv_len[b]):] = 0
             o2[b, int(kv_len[b]):] = 0
-    check_close(f"attention v2 vs v1 {name}", o2, o1.float(), 8e-3, 5e-4)
+    check_close(f"attention v2 vs v1 {name}", o2, o1.float(), 8e-3, 2.5e-3)

@@ -361,55 +361,57 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
         if (t + 1 < t_end) VZ_G_LOAD(t + 1)
         const char* Ks = smem + cur * BUF;
         const char* Vs = Ks + KT * KS;
-        // ---- S^T = K Q^T: sacc[qt][nt][r] = S[key0 + nt*16 + 4g + r][query c of tile qt] ----
-        f32x4 sacc0[NT], sacc1[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            // all DS fragment reads of this key tile are issued before the first MFMA that needs one (their LDS
-            // latency overlaps instead of being paid once per MFMA pair)
-            bf16x8 kf[DS];
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds) kf[ds] = *(const bf16x8*)(Ks + (nt * 16 + c) * KS + ds * 64 + g * 16);
-            sacc0[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            sacc1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds) {
-                sacc0[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ds], qf0[ds], sacc0[nt], 0, 0, 0);
-                sacc1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ds], qf1[ds], sacc1[nt], 0, 0, 0);
-            }
-        }
-        // ---- mask + online softmax per query (lane column) ----
-        bf16x8 pf0[NT / 2], pf1[NT / 2];
-        // the tile is fully visible to this wave's 32 queries when it lies below the causal diagonal of the wave's first
-        // row, inside every row's window and inside the valid keys (wave-uniform)
+        // The 64-key LDS tile is consumed as two 32-key halves: QK^T (2 key tiles) -> online softmax -> PV (one k-step).
+        // Half the live score / probability registers of a 64-key step (no spills at head_dim 128), and the softmax VALU
+        // work of one half sits between MFMA groups of the other.
         const int w_first = p.q_pos0 + q0 + wave * 32, w_last = w_first + 31;
-        const bool full = key0 + KT <= kv_len && (!p.causal || (key0 + KT - 1 <= w_first && (p.window <= 0 || key0 > w_last - p.window)));
-        if (full) {
-            softmax_tile<NT, DT, true>(sacc0, m_run0, l_run0, oacc0, pf0, key0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
-            softmax_tile<NT, DT, true>(sacc1, m_run1, l_run1, oacc1, pf1, key0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
-        } else {
-            softmax_tile<NT, DT, false>(sacc0, m_run0, l_run0, oacc0, pf0, key0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
-            softmax_tile<NT, DT, false>(sacc1, m_run1, l_run1, oacc1, pf1, key0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
-        }
-        // ---- O^T += V^T P^T: the V^T fragment (two transposing reads) feeds both query tiles ----
 #pragma unroll
-        for (int s2 = 0; s2 < NT / 2; ++s2)
+        for (int hf = 0; hf < 2; ++hf) {
+            const int hkey0 = key0 + hf * 32;
+            f32x4 sacc0[2], sacc1[2];
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int nt = hf * 2 + n2;
+                bf16x8 kf[DS];   // all DS fragment reads of a key tile are issued before the first MFMA that needs one
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) kf[ds] = *(const bf16x8*)(Ks + (nt * 16 + c) * KS + ds * 64 + g * 16);
+                sacc0[n2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                sacc1[n2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    sacc0[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ds], qf0[ds], sacc0[n2], 0, 0, 0);
+                    sacc1[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ds], qf1[ds], sacc1[n2], 0, 0, 0);
+                }
+            }
+            bf16x8 pf0[1], pf1[1];
+            // fully visible to this wave's 32 queries: below the causal diagonal of its first row, inside every row's
+            // window, inside the valid keys (wave-uniform)
+            const bool full = hkey0 + 32 <= kv_len && (!p.causal || (hkey0 + 31 <= w_first && (p.window <= 0 || hkey0 > w_last - p.window)));
+            if (full) {
+                softmax_tile<2, DT, true>(sacc0, m_run0, l_run0, oacc0, pf0, hkey0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
+                softmax_tile<2, DT, true>(sacc1, m_run1, l_run1, oacc1, pf1, hkey0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
+            } else {
+                softmax_tile<2, DT, false>(sacc0, m_run0, l_run0, oacc0, pf0, hkey0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
+                softmax_tile<2, DT, false>(sacc1, m_run1, l_run1, oacc1, pf1, hkey0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
+            }
+            // ---- O^T += V^T P^T: each V^T fragment (two transposing reads) feeds both query tiles ----
 #pragma unroll
             for (int d4 = 0; d4 < DT; d4 += 4) {
                 bf16x8 vf[4];      // four V^T fragments (8 transposing reads) in flight before their MFMAs
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const char* vp = Vs + tr_off + (d4 + u) * 32;
-                    const bf16x4 v0 = lds_tr16(vp + (2 * s2) * 16 * VS);
-                    const bf16x4 v1 = lds_tr16(vp + (2 * s2 + 1) * 16 * VS);
+                    const bf16x4 v0 = lds_tr16(vp + (2 * hf) * 16 * VS);
+                    const bf16x4 v1 = lds_tr16(vp + (2 * hf + 1) * 16 * VS);
                     vf[u] = (bf16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    oacc0[d4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], pf0[s2], oacc0[d4 + u], 0, 0, 0);
-                    oacc1[d4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], pf1[s2], oacc1[d4 + u], 0, 0, 0);
+                    oacc0[d4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], pf0[0], oacc0[d4 + u], 0, 0, 0);
+                    oacc1[d4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], pf1[0], oacc1[d4 + u], 0, 0, 0);
                 }
             }
+        }
         if (t + 1 < t_end) VZ_L_STORE(cur ^ 1)
         __syncthreads();
         cur ^= 1;
