@@ -78,45 +78,57 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
 
 // ------------------------------------------------------------------------------------------------
 // RoPE (rotate-half, hf:models/mistral/modeling_mistral.py:51-81) on Q and K of a fused QKV row,
-// K/V appended to the cache [B][Hkv][max_ctx][D].  One wave per (token, head); D = 128:
-// lane l < 32 rotates the pairs (d, d+64) for d = 2l, 2l+1.
+// K/V appended to the cache [B][Hkv][max_ctx][D].  D = 128; 16 lanes x 16 bytes per (token, head).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rope_kv_kernel(const bf16_t* __restrict__ qkv, int ld, bf16_t* __restrict__ q_out,
                                                       bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                       const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                       const int* __restrict__ pos, const int* __restrict__ slot, int B,
                                                       int S, int Hq, int Hkv, int D, int max_ctx) {
-    const int lane = threadIdx.x & 63;
+    // 16 lanes per (token, head): lane `sub` owns the 8 elements d0 = (sub>>3)*64 + (sub&7)*8 .. +7 (one 16-byte access);
+    // the rotation partner (d +- 64) lives in lane sub ^ 8.  Four items per wave, 16 per workgroup.
+    const int lane = threadIdx.x & 63, sub = lane & 15;
     const int heads = Hq + 2 * Hkv;
-    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= (long)B * S * heads) return;
-    const int tok = (int)(item / heads), h = (int)(item % heads);
+    const long item = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const long n_items = (long)B * S * heads;
+    const bool live = item < n_items;
+    const long it = live ? item : n_items - 1;          // keep every lane in the shuffles below
+    const int tok = (int)(it / heads), h = (int)(it % heads);
     const int b = tok / S;
-    const int half = D >> 1;
-    const bf16_t* src = qkv + (size_t)tok * ld + (size_t)h * D;
+    const int d0 = (sub >> 3) * 64 + (sub & 7) * 8;
+    const bf16_t* src = qkv + (size_t)tok * ld + (size_t)h * D + d0;
+    const uint4 raw = *(const uint4*)src;
     const int sl = slot[tok];
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+    unsigned pw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pw[i] = __shfl_xor(w[i], 8, 64);
+    if (!live) return;
     if (h >= Hq + Hkv) {  // V: plain copy into the cache
-        if (sl < 0) return;
-        bf16_t* dst = vc + (((size_t)b * Hkv + (h - Hq - Hkv)) * max_ctx + sl) * D;
-        for (int d = lane * 2; d < D; d += 128) *(unsigned*)(dst + d) = *(const unsigned*)(src + d);
+        if (sl >= 0) *(uint4*)(vc + (((size_t)b * Hkv + (h - Hq - Hkv)) * max_ctx + sl) * D + d0) = raw;
         return;
     }
     bf16_t* dst;
-    if (h < Hq) dst = q_out + ((size_t)tok * Hq + h) * D;
+    if (h < Hq) dst = q_out + ((size_t)tok * Hq + h) * D + d0;
     else {
         if (sl < 0) return;
-        dst = kc + (((size_t)b * Hkv + (h - Hq)) * max_ctx + sl) * D;
+        dst = kc + (((size_t)b * Hkv + (h - Hq)) * max_ctx + sl) * D + d0;
     }
     const int p = pos[tok];
-    for (int d = lane * 2; d < half; d += 128) {
-        const unsigned lo = *(const unsigned*)(src + d), hi = *(const unsigned*)(src + d + half);
-        const float2 c = *(const float2*)(cosT + (size_t)p * half + d), sn = *(const float2*)(sinT + (size_t)p * half + d);
-        const float x0 = bf16_to_f32(lo & 0xFFFF), x1 = bf16_to_f32(lo >> 16);
-        const float y0 = bf16_to_f32(hi & 0xFFFF), y1 = bf16_to_f32(hi >> 16);
-        // out[d] = x*cos - y*sin ; out[d+half] = y*cos + x*sin
-        *(unsigned*)(dst + d) = pack_bf16x2(x0 * c.x - y0 * sn.x, x1 * c.y - y1 * sn.y);
-        *(unsigned*)(dst + d + half) = pack_bf16x2(y0 * c.x + x0 * sn.x, y1 * c.y + x1 * sn.y);
+    const float* cp = cosT + (size_t)p * (D / 2) + (sub & 7) * 8;
+    const float* sp = sinT + (size_t)p * (D / 2) + (sub & 7) * 8;
+    const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4), s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+    const float sgn = (sub >> 3) ? 1.f : -1.f;           // out[d] = x*cos - y*sin ; out[d+64] = y'*cos + x'*sin
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = bf16_to_f32(w[i] & 0xFFFF), x1 = bf16_to_f32(w[i] >> 16);
+        const float y0 = bf16_to_f32(pw[i] & 0xFFFF), y1 = bf16_to_f32(pw[i] >> 16);
+        const float ca = i < 2 ? c0[2 * i] : c1[2 * i - 4], cb = i < 2 ? c0[2 * i + 1] : c1[2 * i - 3];
+        const float sa = i < 2 ? s0[2 * i] : s1[2 * i - 4], sb = i < 2 ? s0[2 * i + 1] : s1[2 * i - 3];
+        o[i] = pack_bf16x2(x0 * ca + sgn * (y0 * sa), x1 * cb + sgn * (y1 * sb));
     }
+    *(uint4*)dst = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,7 +313,7 @@ int vz_launch_rope_kv(const bf16_t* qkv, int ld, bf16_t* q_out, bf16_t* kc, bf16
                       const int* pos, const int* slot, int B, int S, int Hq, int Hkv, int D, int max_ctx, hipStream_t s) {
     VZ_CHECK_ARG(D == 128, "rope: head_dim %d unsupported (Zephyr uses 128)", D);
     const long items = (long)B * S * (Hq + 2 * Hkv);
-    hipLaunchKernelGGL(rope_kv_kernel, dim3(rows_grid(items)), dim3(256), 0, s, qkv, ld, q_out, kc, vc, cosT, sinT, pos, slot, B,
+    hipLaunchKernelGGL(rope_kv_kernel, dim3((int)((items + 15) / 16)), dim3(256), 0, s, qkv, ld, q_out, kc, vc, cosT, sinT, pos, slot, B,
                        S, Hq, Hkv, D, max_ctx);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
