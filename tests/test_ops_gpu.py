@@ -387,3 +387,22 @@ def test_attention_v2_matches_v1(B, case):
             o1[b, int(kv_len[b]):] = 0
             o2[b, int(kv_len[b]):] = 0
     check_close(f"attention v2 vs v1 {name}", o2, o1.float(), 8e-3, 2.5e-3)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(160, 4096, 4096, 0), (160, 8192, 4096, 2), (32, 12288, 4096, 0), (4, 4096, 14336, 0), (512, 4096, 8192, 0)])
+def test_gemm_splitk_small_m(B, M, N, K, act):
+    """Q-Former-shaped products (few row tiles, long K) run split-K: slices of K per tile, fp32 slabs, one finalize pass."""
+    x = _rand((M, K), 1.0, 80).bfloat16()
+    w = _rand((N, K), 0.03, 81).bfloat16()
+    bias = _rand((N,), 0.3, 82)
+    res = _rand((M, N), 1.0, 83).bfloat16()
+    out = B.linear(x, w, bias=bias, residual=res, act=act, impl=0)
+    check_close(f"gemm split-K {M}x{N}x{K}", out, _ref_linear(x, w, bias, res, act), BF16_MAX, BF16_L2)
+    try:
+        B.check(B.lib().vz_tune_set(3, 1))
+        plain = B.linear(x, w, bias=bias, residual=res, act=act, impl=0)
+    finally:
+        B.check(B.lib().vz_tune_set(3, 0))
+    check_close(f"gemm split-K vs single pass {M}x{N}x{K}", out, plain.float(), 8e-3, 5e-4)
+    o32 = B.linear(x, w, out_fp32=True, impl=0)
+    check_close(f"gemm split-K fp32 {M}x{N}x{K}", o32, _ref_linear(x, w, None, None, 0), 1e-4, 1e-4)

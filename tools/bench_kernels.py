@@ -70,6 +70,11 @@ def bench_gemm():
         x = torch.randn(M, K, device=dev).bfloat16()
         ws = [torch.randn(N, K, device=dev).bfloat16() * 0.02 for _ in range(3)]
         row = []
+        if M <= 512:
+            B.check(B.lib().vz_tune_set(3, 1))
+            us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act, impl=0), 12) for _ in range(3))
+            B.check(B.lib().vz_tune_set(3, 0))
+            row.append(f"128 no-splitK: {us:8.1f} us")
         for impl in (0, 2):
             us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act, impl=impl), 12) for _ in range(3))
             tf = 2.0 * M * N * K / us / 1e6

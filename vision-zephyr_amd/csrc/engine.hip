@@ -803,6 +803,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 0) { vz_set_gemv_variant(value); return VZ_OK; }
     if (knob == 1) { vz_set_gemm_choice(value); return VZ_OK; }
     if (knob == 2) { vz_set_attn_version(value); return VZ_OK; }
+    if (knob == 3) { vz_set_splitk_mode(value); return VZ_OK; }
     vz_set_error("tune_set: unknown knob %d", knob);
     return VZ_ERR_ARG;
 }

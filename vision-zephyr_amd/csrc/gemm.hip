@@ -31,6 +31,7 @@ struct GemmParams {
     const float* bias; const bf16_t* residual;
     int M, N, K, lda, ldw, ldc, ldr;
     int act, out_fp32, tiles_m, tiles_n;
+    int splitk; float* slab;   // splitk > 1: fp32 partial tiles go to slab[split][M][N], epilogue runs in splitk_finalize_kernel
 };
 
 __device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     // XCD-aware, bijective tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a
     // contiguous run of tiles; inside a run tiles walk M first, i.e. neighbours share one W panel.
     const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
+    const int split = blockIdx.x / nwg;              // split-K slices of one tile are launched nwg blocks apart
+    const int bid = blockIdx.x - split * nwg;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int bn = tile / p.tiles_m, bm = tile - bn * p.tiles_m;
@@ -85,8 +87,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
-    auto stage = [&](int buf, int kt) {
+    const int nk_all = p.K / BK;
+    const int k_lo = (int)((long)nk_all * split / p.splitk), k_hi = (int)((long)nk_all * (split + 1) / p.splitk);
+    const int nk = k_hi - k_lo;
+    auto stage = [&](int buf, int kt_rel) {
+        const int kt = k_lo + kt_rel;
         char* la = smem + buf * BUF_BYTES + wave_chunk;
         char* lw = la + TILE_BYTES;
         const int kb = kt * (BK * 2);
@@ -127,6 +132,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     // ---- epilogue: acc[nt][mt][j] = C[m = .. + mt*16 + (lane&15)][n = .. + nt*16 + 4*(lane>>4) + j] ----
     const int m_base = bm * BM + wm * 64 + frow;
     const int n_base = bn * BN + wn * 64 + g * 4;
+    if (p.splitk > 1) {   // raw fp32 partial sums; bias / activation / residual / rounding happen once, in the finalize kernel
+        float* slab = p.slab + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m_base + mt * 16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n0 = n_base + nt * 16;
+                if (n0 + 3 < p.N && (p.N & 3) == 0) *(f32x4*)(slab + (size_t)m * p.N + n0) = acc[nt][mt];
+                else
+                    for (int j = 0; j < 4; ++j)
+                        if (n0 + j < p.N) slab[(size_t)m * p.N + n0 + j] = acc[nt][mt][j];
+            }
+        }
+        return;
+    }
     const bool swiglu = p.act == VZ_ACT_SWIGLU;
     const int n_out_total = swiglu ? p.N / 2 : p.N;
     const bool vec_ok = (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0);
@@ -182,6 +204,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
+// sum of the split-K slabs + the fused epilogue (bias / activation / residual / bf16|fp32 out), 4 outputs per thread
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmParams p) {
+    const long quads = (long)p.M * (p.N / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < quads; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / (p.N / 4)), n0 = (int)(i % (p.N / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < p.splitk; ++s2) v += *(const f32x4*)(p.slab + ((size_t)s2 * p.M + m) * p.N + n0);
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = v[j];
+            if (p.bias) t += p.bias[n0 + j];
+            t = apply_act(t, p.act);
+            if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + n0 + j]);
+            o[j] = t;
+        }
+        if (p.out_fp32) {
+            float* c = (float*)p.C + (size_t)m * p.ldc + n0;
+            c[0] = o[0]; c[1] = o[1]; c[2] = o[2]; c[3] = o[3];
+        } else {
+            bf16_t* c = (bf16_t*)p.C + (size_t)m * p.ldc + n0;
+            c[0] = f32_to_bf16(o[0]); c[1] = f32_to_bf16(o[1]); c[2] = f32_to_bf16(o[2]); c[3] = f32_to_bf16(o[3]);
+        }
+    }
+}
+
 }  // namespace
 
 int vz_linear_check_common(const LinearArgs& a) {
@@ -203,9 +251,15 @@ int vz_linear_check_common(const LinearArgs& a) {
     return VZ_OK;
 }
 
+static float* g_slab;
+static size_t g_slab_bytes;
 int vz_init_gemm_kernels() {
     static bool done = false;
     if (done) return VZ_OK;
+    if (!g_slab) {   // split-K workspace for every shape a captured decode step can reach (M <= 8) and the Q-Former's (M <= 512)
+        VZ_CHECK_HIP(hipMalloc((void**)&g_slab, (size_t)96 << 20));
+        g_slab_bytes = (size_t)96 << 20;
+    }
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
     { int r = vz_init_gemv_kernels(); if (r) return r; r = vz_init_gemm256_kernel(); if (r) return r; }
     done = true;
@@ -214,6 +268,9 @@ int vz_init_gemm_kernels() {
 
 static int g_gemm_choice = 0;
 void vz_set_gemm_choice(int v) { g_gemm_choice = v; }
+static int g_splitk_mode = 0;          // 0 auto, 1 never (A/B knob 3)
+void vz_set_splitk_mode(int v) { g_splitk_mode = v; }
+// g_slab / g_slab_bytes (declared above): process-wide split-K workspace, 96 MiB up front, grown on demand outside captures
 
 // Tile choice: the 256x256 8-phase kernel runs one workgroup per CU, so it needs enough 256^2 tiles to fill the
 // 256 CUs several times over (>= 512 tiles: measured cross-over on MI355X, tools/bench_kernels.py); smaller grids keep the
@@ -235,8 +292,34 @@ int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;
     { int r = vz_init_gemm_kernels(); if (r) return r; }
-    vz_launch_timed(gemm_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), GEMM_LDS, s, p);
+    // Split-K for weight-streaming shapes (M <= 512: Q-Former projections at 32 rows per tile): with a handful of row tiles
+    // the grid cannot fill 256 CUs, so K is cut into up to 4 slices per tile; the fp32 slabs cost 2 x 4 x M x N x splitk bytes
+    // of extra traffic, small next to the weights only while M is small.
+    const int tiles = p.tiles_m * p.tiles_n, nk = a.K / BK;
+    int splitk = 1;
+    if (g_splitk_mode != 1 && a.M <= 512 && tiles < 256 && a.act != VZ_ACT_SWIGLU && (a.N & 3) == 0) {
+        splitk = (384 + tiles - 1) / tiles;
+        if (splitk > 4) splitk = 4;
+        while (splitk > 1 && nk / splitk < 8) --splitk;
+    }
+    p.splitk = splitk; p.slab = nullptr;
+    if (splitk > 1) {
+        const size_t need = (size_t)splitk * a.M * a.N * sizeof(float);
+        if (need > g_slab_bytes) {
+            if (g_slab) { VZ_CHECK_HIP(hipDeviceSynchronize()); VZ_CHECK_HIP(hipFree(g_slab)); g_slab = nullptr; g_slab_bytes = 0; }
+            VZ_CHECK_HIP(hipMalloc((void**)&g_slab, need));
+            g_slab_bytes = need;
+        }
+        p.slab = g_slab;
+    }
+    vz_launch_timed(gemm_bf16_kernel, dim3(tiles * splitk), dim3(256), GEMM_LDS, s, p);
     VZ_LAUNCH_CHECK();
+    if (splitk > 1) {
+        long blocks = ((long)a.M * (a.N / 4) + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_finalize_kernel, dim3((int)blocks), dim3(256), 0, s, p);
+        VZ_LAUNCH_CHECK();
+    }
     return VZ_OK;
 }
 

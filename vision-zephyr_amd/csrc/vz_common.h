@@ -103,7 +103,8 @@ int vz_launch_gemv(const LinearArgs& a, hipStream_t s);
 int vz_launch_gemm128(const LinearArgs& a, hipStream_t s);
 int vz_launch_gemm256(const LinearArgs& a, hipStream_t s);
 int vz_init_gemm256_kernel();
-void vz_set_gemm_choice(int v);   // 0 auto, 1 force 128x128, 2 force 256x256
+void vz_set_gemm_choice(int v);
+void vz_set_splitk_mode(int v);   // 0 auto, 1 force 128x128, 2 force 256x256
 int vz_launch_linear(const LinearArgs& a, hipStream_t s);  // picks by M
 
 int vz_launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const float* w, const float* b, int rows,
