@@ -198,7 +198,9 @@ int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d_logits_dbg
 int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_stream stream);
 
 /* tuning hook for tools/bench_kernels.py: knob 0 = GEMV variant (0 = production choice, 1.. = alternatives
- * compiled into the library: rows per wave, chunks in flight, non-temporal loads).  Process-wide. */
+ * compiled into the library: rows per wave, chunks in flight, non-temporal loads), 1 = GEMM kernel choice,
+ * 2 = prefill attention generation, 3 = split-K mode, 4 = 256^2 GEMM stream-K tail (1 = on, 0 = whole tiles only), 5 = stream-K skew in K-tiles, 6 = record 256^2 GEMM phase stamps.
+ * Process-wide. */
 int vz_tune_set(int knob, int value);
 
 /* per-kernel-class timing of the engine's launches with HIP events on the launch stream (bench.py's roofline
@@ -207,6 +209,9 @@ int vz_tune_set(int knob, int value);
 int vz_prof_enable(vz_engine* e, int enable, int klass);
 /* synchronises the events; returns launches counted and their total milliseconds */
 int vz_prof_read(vz_engine* e, long* n_launches, double* total_ms);
+/* in-kernel phase stamps (s_memrealtime, 100 MHz) of the last 256^2 GEMM launched with vz_tune_set(6, 1):
+ * 16 int64 per workgroup = {start, then per K-slice: loop begin, loop end, fix-up end, epilogue end, (nk<<32 | flags)} */
+int vz_prof_gemm_stamps(long long* host_out, int max_wgs, int* n_wgs);
 
 #ifdef __cplusplus
 }

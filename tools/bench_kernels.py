@@ -75,11 +75,35 @@ def bench_gemm():
             us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act, impl=0), 12) for _ in range(3))
             B.check(B.lib().vz_tune_set(3, 0))
             row.append(f"128 no-splitK: {us:8.1f} us")
-        for impl in (0, 2):
+        for impl, sk in ((0, 0), (2, 0), (2, 2)):
+            B.check(B.lib().vz_tune_set(4, sk))
             us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act, impl=impl), 12) for _ in range(3))
             tf = 2.0 * M * N * K / us / 1e6
-            row.append(f"{'128' if impl == 0 else '256'}: {us:8.1f} us {tf:7.1f} TF ({tf / 2500 * 100:4.1f}%)")
+            row.append(f"{'128' if impl == 0 else ('256sk' if sk else '256')}: {us:8.1f} us {tf:7.1f} TF ({tf / 2500 * 100:4.1f}%)")
+        B.check(B.lib().vz_tune_set(4, 1))
+        us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act), 12) for _ in range(3))
+        row.append(f"dispatch: {us:8.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF")
         print(f"gemm {name:12s} M{M} N{N} K{K}: " + "   ".join(row), flush=True)
+
+
+def bench_gemm_square():
+    """Full-round shapes: the guide quotes its 256^2 template at 4096^3 / 8192^3 on random operands."""
+    shapes = [("4k^3", 4096, 4096, 4096, 0), ("8k^3", 8192, 8192, 8192, 0), ("4 rounds", 2048, 32768, 4096, 0),
+              ("3.5 rounds", 2048, 28672, 4096, 0), ("3 rounds", 2048, 24576, 4096, 0), ("down 256", 2048, 4096, 14336, 0)]
+    for name, M, N, K, act in shapes:
+        x = torch.rand(M, K, device=dev).bfloat16() * 2 - 1
+        ws = [(torch.rand(N, K, device=dev) * 2 - 1).bfloat16() for _ in range(2)]
+        row = []
+        for impl, ring in ((0, 0), (2, 0), (2, 1)):      # 256 kernel without / with the stream-K tail
+            B.check(B.lib().vz_tune_set(4, ring))
+            us = min(timed(lambda i: B.linear(x, ws[i % 2], act=act, impl=impl), 10) for _ in range(3))
+            tf = 2.0 * M * N * K / us / 1e6
+            row.append(f"{'128' if impl == 0 else ('256sk' if ring else '256')}: {us:8.1f} us {tf:7.1f} TF")
+        B.check(B.lib().vz_tune_set(4, 1))
+        us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act), 12) for _ in range(3))
+        row.append(f"dispatch: {us:8.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF")
+        print(f"gemm {name:12s} M{M} N{N} K{K}: " + "   ".join(row), flush=True)
+        del ws
 
 
 def bench_attn():
@@ -133,5 +157,7 @@ if __name__ == "__main__":
         bench_gemv()
     if what in ("gemm", "all"):
         bench_gemm()
+    if what == "gemmsq":
+        bench_gemm_square()
     if what in ("attn", "all"):
         bench_attn()

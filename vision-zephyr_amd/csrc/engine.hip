@@ -799,13 +799,22 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     return VZ_OK;
 }
 
+extern int g_gemm256_streamk, g_gemm256_skew, g_gemm256_stamps;
+int vz_gemm256_read_stamps(long long* host, int max_wgs, int* n_wgs);
 extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 0) { vz_set_gemv_variant(value); return VZ_OK; }
     if (knob == 1) { vz_set_gemm_choice(value); return VZ_OK; }
     if (knob == 2) { vz_set_attn_version(value); return VZ_OK; }
     if (knob == 3) { vz_set_splitk_mode(value); return VZ_OK; }
+    if (knob == 4) { g_gemm256_streamk = value; return VZ_OK; }
+    if (knob == 5) { g_gemm256_skew = value; return VZ_OK; }
+    if (knob == 6) { g_gemm256_stamps = value; return VZ_OK; }
     vz_set_error("tune_set: unknown knob %d", knob);
     return VZ_ERR_ARG;
+}
+
+extern "C" int vz_prof_gemm_stamps(long long* host_out, int max_wgs, int* n_wgs) {
+    return vz_gemm256_read_stamps(host_out, max_wgs, n_wgs);
 }
 
 extern "C" int vz_prof_enable(vz_engine* e, int enable, int klass) {

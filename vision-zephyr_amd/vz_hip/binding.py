@@ -66,6 +66,7 @@ SYMBOLS = {
     "vz_tune_set": (_I, [_I, _I]),
     "vz_prof_enable": (_I, [_P, _I, _I]),
     "vz_prof_read": (_I, [_P, C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "vz_prof_gemm_stamps": (_I, [C.POINTER(C.c_longlong), _I, C.POINTER(_I)]),
 }
 
 _lib: Optional[C.CDLL] = None
