@@ -153,6 +153,11 @@ int vz_engine_finalize(vz_engine* e);
  * every rank calls vz_comm_init with it before its first prefill. */
 int vz_comm_unique_id(char* out128);
 int vz_comm_init(vz_engine* e, const char* id128);
+/* Tile data parallelism (first row): every anyres tile is an independent unit through CLIP, fusion and
+ * the Q-Former, so the host deals tile t to rank t mod tp_size, each rank encodes its tiles, and ONE all-gather of
+ * bytes_per_rank bytes per rank (ceil(T / tp_size) x 32 x hidden bf16, zero-padded) hands every rank all visual tokens.
+ * d_recv holds tp_size consecutive chunks in rank order.  At tp_size == 1 this is a device copy. */
+int vz_tp_all_gather(vz_engine* e, const void* d_send, void* d_recv, size_t bytes_per_rank, vz_stream stream);
 
 /* fp32 rotary tables [max_pos, head_dim/2] (rotate-half convention, hf:...modeling_mistral.py:51-81,262-317) */
 int vz_engine_set_rope(vz_engine* e, const float* d_cos, const float* d_sin, int max_pos);
@@ -199,7 +204,8 @@ int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_strea
 
 /* tuning hook for tools/bench_kernels.py: knob 0 = GEMV variant (0 = production choice, 1.. = alternatives
  * compiled into the library: rows per wave, chunks in flight, non-temporal loads), 1 = GEMM kernel choice,
- * 2 = prefill attention generation, 3 = split-K mode, 4 = 256^2 GEMM stream-K tail (1 = on, 0 = whole tiles only), 5 = stream-K skew in K-tiles, 6 = record 256^2 GEMM phase stamps.
+ * 2 = prefill attention generation, 3 = split-K mode, 4 = 256^2 GEMM stream-K tail (1 = on, 0 = whole tiles only), 5 = stream-K skew in K-tiles, 6 = record 256^2 GEMM phase stamps,
+ * 7 = route the collectives of a tp_size == 1 engine that holds a one-rank communicator through RCCL (self-test).
  * Process-wide. */
 int vz_tune_set(int knob, int value);
 

@@ -77,6 +77,58 @@ def _worker(rank, world, port, out_q):
         dist.destroy_process_group()
 
 
+def _tile_dp_worker(rank, world, port, out_q):
+    """tile data parallelism of CLIP + fusion + Q-Former: the plan of vz_hip/tp.py with the oracle as the encoder."""
+    for p in (REPO, os.path.join(REPO, "vision-zephyr_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import vz_oracle as O
+        from vz_hip import synth, tp
+        torch.set_num_threads(2)
+        # a narrow model of the same shape: 24 CLIP layers (the fusion reads the last 21 hidden states), 8 Q-Former blocks
+        cfg = synth.ArchConfig(hidden=128, clip_hidden=64, clip_inter=128, clip_heads=4, clip_image=56, qf_heads=4, qf_kv_dim=320)
+        sd = synth.state_dict(cfg, 0, prefixes=("model.vision_tower", "model.mm_projector"))
+        worst = 0.0
+        for T in (1, 3, 5):                       # fewer tiles than ranks, odd counts, the 5-tile anyres case
+            tiles = synth.synth_tiles(T, seed=7, size=cfg.clip_image)
+            text = synth.hash_normal("text", (T, 6, cfg.hidden), 1.0, 4)
+            mine = tp.local_tiles(T, rank, world)
+            per = tp.tiles_per_rank(T, world)
+            send = torch.zeros(per, cfg.qf_queries, cfg.hidden)
+            if mine:
+                send[:len(mine)] = O.encode_images(cfg, sd, tiles[mine], text[mine], O.FP32)
+            got = [torch.zeros_like(send) for _ in range(world)]
+            dist.all_gather(got, send)
+            out = torch.cat(got, 0)[tp.gathered_index(T, world)]
+            ref = O.encode_images(cfg, sd, tiles, text, O.FP32)
+            assert out.shape == ref.shape
+            worst = max(worst, float((out - ref).abs().max() / ref.abs().max()))
+        out_q.put((rank, worst))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_tile_data_parallel_plan_matches_unsharded_oracle():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_tile_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err in res:
+        assert err < 1e-5, (rank, err)
+
+
 @pytest.mark.timeout(300)
 def test_tp2_sharding_plan_matches_unsharded_oracle():
     world = 2
@@ -112,6 +164,14 @@ def test_shard_kinds_and_ranges():
         assert spans[0][0] == 0 and spans[-1][1] == 32001 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     with pytest.raises(ValueError):
         tp.check_divisible(cfg, 3)
+    for T in (1, 4, 5, 64):
+        for w in (1, 2, 4, 8):
+            owned = sorted(t for r in range(w) for t in tp.local_tiles(T, r, w))
+            assert owned == list(range(T))
+            per = tp.tiles_per_rank(T, w)
+            assert all(len(tp.local_tiles(T, r, w)) <= per for r in range(w))
+            gi = tp.gathered_index(T, w).tolist()
+            assert gi == [(t % w) * per + t // w for t in range(T)] and len(set(gi)) == T
     t = torch.arange(8 * 6).view(8, 6)
     assert torch.equal(torch.cat([tp.shard("model.layers.0.mlp.up_proj.weight", t, r, 2) for r in range(2)], 0), t)
     assert torch.equal(torch.cat([tp.shard("model.layers.0.self_attn.o_proj.weight", t, r, 2) for r in range(2)], 1), t)

@@ -67,3 +67,97 @@ def test_tp2_shards_reproduce_single_gpu_prefill():
     check_close("tp2 shards vs tp1 engine logits", got, ref[0], 2e-2, 6e-3)
     for e in shards + [full]:
         e.close()
+
+
+def test_tile_data_parallel_encode_matches_unsharded():
+    """Tile data parallelism of CLIP + fusion + Q-Former through the production code path
+    (`_encode_images_tile_dp`): the two ranks of a tp_size=2 group are played one after the other on this GPU, the RCCL
+    all-gather is replaced by stacking the two ranks' send buffers (the layout vz_tp_all_gather produces).  With the
+    batch-invariant kernel choice (128x128 GEMM, no stream-K: a tile's result does not depend on the tiles beside it)
+    the gathered visual tokens must be BIT-IDENTICAL to the unsharded encode; with the production dispatch they must
+    agree within bf16 rounding of the 8-block Q-Former."""
+    from vz_hip import binding as B, synth
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    cfg = synth.ArchConfig(n_layers=1, vocab=1001)
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.n_layers,
+                         num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab,
+                         rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, sliding_window=cfg.sliding_window,
+                         eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    hf.mm_hidden_size = 5120
+    hf.mm_vision_select_feature = "patch"
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=256, max_tiles=5, max_text=16)
+    eng = model.engine
+    T = 5
+    tiles = synth.synth_tiles(T, seed=1).to(model.device).bfloat16()
+    text = synth.hash_normal("text", (2, 9, cfg.hidden), 1.0, 4).to(model.device).bfloat16()     # two samples: 3 + 2 tiles
+    tile_sample = [0, 0, 0, 1, 1]
+
+    def tile_dp():
+        sends = {}
+        real_gather = eng.all_gather
+        try:
+            eng.tp_size = 2
+            for r in range(2):                                   # pass 1: what each rank would put on the wire
+                eng.tp_rank = r
+                eng.all_gather = lambda send, r=r: (sends.__setitem__(r, send.clone()), torch.zeros((2,) + tuple(send.shape), dtype=send.dtype, device=send.device))[1]
+                model.encode_images(tiles, text, tile_sample=tile_sample)
+            assert sends[0].shape == sends[1].shape == (3, cfg.qf_queries, cfg.hidden)
+            assert float(sends[1][2].float().abs().max()) == 0.0          # rank 1 owns tiles 1, 3: its third slot is padding
+            eng.all_gather = lambda send: torch.stack([sends[0], sends[1]])
+            outs = []
+            for r in range(2):                                   # pass 2: both ranks end up with all visual tokens
+                eng.tp_rank = r
+                outs.append(model.encode_images(tiles, text, tile_sample=tile_sample))
+            assert torch.equal(outs[0], outs[1])
+            return outs[0]
+        finally:
+            eng.tp_size, eng.tp_rank, eng.all_gather = 1, 0, real_gather
+
+    try:
+        B.check(B.lib().vz_tune_set(1, 1))       # 128x128 kernel only
+        B.check(B.lib().vz_tune_set(4, 0))
+        ref = model.encode_images(tiles, text, tile_sample=tile_sample)
+        assert ref.shape == (T, cfg.qf_queries, cfg.hidden)
+        assert torch.equal(tile_dp(), ref), "tile-data-parallel encode differs from the unsharded one"
+    finally:
+        B.check(B.lib().vz_tune_set(1, 0))
+        B.check(B.lib().vz_tune_set(4, 1))
+    ref = model.encode_images(tiles, text, tile_sample=tile_sample)
+    check_close("tile-DP vs unsharded (production dispatch)", tile_dp(), ref.float(), 0.25, 2e-2)
+    # the C-ABI all-gather at tp_size 1 is a device copy into chunk 0
+    got = eng.all_gather(ref[:2])
+    assert got.shape == (1, 2, cfg.qf_queries, cfg.hidden) and torch.equal(got[0], ref[:2])
+
+
+def test_rccl_call_sites_on_one_rank():
+    """The RCCL plumbing on ONE GPU: a tp_size == 1 engine gets a one-rank communicator and vz_tune_set(7, 1) routes its
+    collective call sites through RCCL - 2 bf16 all-reduces per layer in prefill and in every decode step (in place, on the
+    engine's stream), the vocab-parallel fp32 all-gather + repack of the logits, and vz_tp_all_gather.  Over one rank
+    every collective is the identity, so logits and generated ids must be bit-identical to the plain path."""
+    from vz_hip import binding as B, synth
+    from vz_hip.engine import Engine
+    cfg = synth.ArchConfig(n_layers=2, vocab=1001, clip_layers=20)
+    eng = Engine(cfg, max_ctx=128, max_tiles=1, max_text=8)
+    eng.load_synthetic(0)
+    S = 40
+    ids = synth.synth_ids(S, cfg.vocab, image_pos=-1, seed=5)
+    x = eng.embed_tokens(ids).unsqueeze(0)
+
+    def run():
+        all_logits, last = eng.prefill(x, [S], all_logits=True, last_logits=True)
+        eng.decode_begin(last.argmax(-1).to(torch.int32), [S], [S])
+        return all_logits.clone(), eng.decode_steps(6).clone()
+
+    ref_logits, ref_ids = run()
+    eng.init_comm_single_rank()
+    try:
+        B.check(B.lib().vz_tune_set(7, 1))
+        logits, new_ids = run()
+        gathered = eng.all_gather(x[0, :3])
+    finally:
+        B.check(B.lib().vz_tune_set(7, 0))
+    assert torch.equal(logits, ref_logits)
+    assert torch.equal(new_ids, ref_ids)
+    assert gathered.shape == (1, 3, cfg.hidden) and torch.equal(gathered[0], x[0, :3])

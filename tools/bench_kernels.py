@@ -61,6 +61,25 @@ def bench_gemv():
     return res
 
 
+def bench_gemv_resident():
+    """Does a GEMV run faster when its weights sit in the 256 MiB Infinity Cache (read by the previous kernel) than from
+    HBM?  Same weights every launch (resident) vs a pool larger than the cache (streamed), per shape."""
+    for name, N, K, act in [("o", 4096, 4096, 0), ("qkv", 6144, 4096, 0), ("down", 4096, 14336, 0), ("gate-up", 28672, 4096, 3)]:
+        n_out = N // 2 if act == 3 else N
+        x = torch.randn(1, K, device=dev).bfloat16()
+        out = torch.empty(1, n_out, dtype=torch.bfloat16, device=dev)
+        st = B.stream_ptr()
+        fn = B.lib().vz_op_linear_impl
+        pool = max(2, int(1.2e9 // (N * K * 2)))
+        ws = [torch.randn(N, K, device=dev).bfloat16() * 0.02 for _ in range(pool)]
+        argl = [(1, B.ptr(x), K, B.ptr(w), K, B.ptr(out), n_out, 1, N, K, None, None, 0, act, 0, st) for w in ws]
+        mb = N * K * 2 / 1e6
+        us_stream = min(timed(lambda i: fn(*argl[i % pool]), 4 * pool) for _ in range(3))
+        us_res = min(timed(lambda i: fn(*argl[0]), 4 * pool) for _ in range(3))
+        print(f"gemv {name:8s} {mb:6.1f} MB: streamed {us_stream:6.1f} us {mb / us_stream:5.2f} TB/s   resident {us_res:6.1f} us {mb / us_res:5.2f} TB/s", flush=True)
+        del ws
+
+
 def bench_gemm():
     shapes = [("llm qkv", 2048, 6144, 4096, 0), ("llm o", 2048, 4096, 4096, 0), ("llm gate-up", 2048, 28672, 4096, 3),
               ("llm down", 2048, 4096, 14336, 0), ("clip qkv", 2885, 3072, 1024, 0), ("clip fc1", 2885, 4096, 1024, 1),
@@ -157,6 +176,8 @@ if __name__ == "__main__":
         bench_gemv()
     if what in ("gemm", "all"):
         bench_gemm()
+    if what == "gemvres":
+        bench_gemv_resident()
     if what == "gemmsq":
         bench_gemm_square()
     if what in ("attn", "all"):

@@ -553,8 +553,14 @@ extern "C" int vz_embed_splice(vz_engine* e, const int* d_kind, const int* d_idx
 
 
 // ---- tensor-parallel collectives (RCCL over xGMI); no-ops at tp == 1 ----
+// Self-test (vz_tune_set(7, 1)): an engine with tp_size == 1 that has been given a one-rank communicator routes the same
+// call sites through RCCL (all-reduce over one rank = identity, all-gather = copy), so the collective plumbing - library,
+// dtypes, in-place buffers, stream order, the vocab-parallel gather + repack - runs on a single GPU.
+static int g_force_comm = 0;
+static inline bool tp_local(const vz_engine* e) { return e->tp == 1 && !(g_force_comm && e->comm); }
+
 static int tp_allreduce_bf16(vz_engine* e, bf16_t* buf, size_t count, hipStream_t s) {
-    if (e->tp == 1) return VZ_OK;
+    if (tp_local(e)) return VZ_OK;
     if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
     ProfScope ps(e, K_OTHER, s);
     ncclResult_t r = ncclAllReduce(buf, buf, count, ncclBfloat16, ncclSum, e->comm, s);
@@ -570,14 +576,15 @@ static int lm_head_logits(vz_engine* e, const bf16_t* h, int rows, float* out, h
     int rc = VZ_OK;
     const bf16_t* lm = WB("llm.lm_head", (long)e->Vp * H);
     if (rc) return rc;
-    if (e->tp == 1) return linear(e, 0, h, H, lm, H, out, c.vocab, rows, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps);
-    const size_t need = (size_t)(e->tp + 1) * rows * e->Vp;
+    if (tp_local(e)) return linear(e, 0, h, H, lm, H, out, c.vocab, rows, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps);
+    const size_t local_off = ((size_t)e->tp * rows * e->Vp + 3) & ~(size_t)3;      // the GEMM wants a 16-byte-aligned output base
+    const size_t need = local_off + (size_t)rows * e->Vp;
     if (need > e->gather_floats) {
         if (e->d_gather) { VZ_CHECK_HIP(hipStreamSynchronize(s)); VZ_CHECK_HIP(hipFree(e->d_gather)); e->d_gather = nullptr; }
         VZ_CHECK_HIP(hipMalloc((void**)&e->d_gather, need * sizeof(float)));
         e->gather_floats = need;
     }
-    float* local = e->d_gather + (size_t)e->tp * rows * e->Vp;
+    float* local = e->d_gather + local_off;
     RC(linear(e, 0, h, H, lm, H, local, e->Vp, rows, e->Vp, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps));
     if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
     ncclResult_t r = ncclAllGather(local, e->d_gather, (size_t)rows * e->Vp, ncclFloat, e->comm, s);
@@ -602,6 +609,17 @@ extern "C" int vz_comm_init(vz_engine* e, const char* id128) {
     memcpy(&id, id128, 128);
     ncclResult_t r = ncclCommInitRank(&e->comm, e->tp, id, e->rank);
     if (r != ncclSuccess) { e->comm = nullptr; vz_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
+    return VZ_OK;
+}
+
+extern "C" int vz_tp_all_gather(vz_engine* e, const void* d_send, void* d_recv, size_t bytes_per_rank, vz_stream stream) {
+    VZ_CHECK_ARG(e && d_send && d_recv && bytes_per_rank > 0, "tp_all_gather: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (tp_local(e)) { VZ_CHECK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, s)); return VZ_OK; }
+    if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
+    ProfScope ps(e, K_OTHER, s);
+    ncclResult_t r = ncclAllGather(d_send, d_recv, bytes_per_rank, ncclInt8, e->comm, s);
+    if (r != ncclSuccess) { vz_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
     return VZ_OK;
 }
 
@@ -773,7 +791,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     const int B = e->dec_B;
     const size_t need = ((size_t)B * (3 * c.hidden + (c.n_heads + 2 * c.n_kv_heads) * c.head_dim + c.inter)) * 2 + 8192;   // upper bound (tp = 1 sizes)
     RC(ensure_arena(e, need));
-    const bool use_graph = !e->prof_on && !d_logits_dbg && e->tp == 1 && getenv("VZ_NO_GRAPH") == nullptr;   // collectives run eagerly
+    const bool use_graph = !e->prof_on && !d_logits_dbg && tp_local(e) && getenv("VZ_NO_GRAPH") == nullptr;   // collectives run eagerly
     int* step = e->d_state + 4 * c.max_batch;
     VZ_CHECK_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
     if (!use_graph) {
@@ -809,6 +827,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 4) { g_gemm256_streamk = value; return VZ_OK; }
     if (knob == 5) { g_gemm256_skew = value; return VZ_OK; }
     if (knob == 6) { g_gemm256_stamps = value; return VZ_OK; }
+    if (knob == 7) { g_force_comm = value; return VZ_OK; }
     vz_set_error("tune_set: unknown knob %d", knob);
     return VZ_ERR_ARG;
 }

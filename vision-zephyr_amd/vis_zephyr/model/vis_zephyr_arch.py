@@ -44,8 +44,35 @@ class VisZephyrMetaForCausalLM:
     def encode_images(self, images, text_embeddings, tile_sample: Optional[Sequence[int]] = None):
         """images [T,3,336,336], text_embeddings [T,Lmax,4096] (or [n_samples,Lmax,4096] together with
         `tile_sample`) -> [T,32,4096]   (ref vis_zephyr_arch.py:120-124)."""
+        eng = getattr(self, "engine", None)
+        if eng is not None and eng.tp_size > 1 and getattr(self, "tile_data_parallel", True):
+            return self._encode_images_tile_dp(images, text_embeddings, tile_sample)
         feats = self.get_model().get_vision_tower()(images)
         return self.get_model().mm_projector(feats, text_embeddings=text_embeddings, tile_sample=tile_sample)
+
+    def _encode_images_tile_dp(self, images, text_embeddings, tile_sample):
+        """Every tile is an independent unit through CLIP, fusion and the Q-Former (the Q-Former conditions a tile on its
+        own sample's text only, ref vis_zephyr_arch.py:163-176): rank r of the tensor-parallel group encodes tiles
+        r, r+tp, r+2tp, ... and ONE RCCL all-gather of [ceil(T/tp),32,4096] bf16 per rank hands every rank all visual
+        tokens.  Every rank takes part in the collective, also with no tile of its own."""
+        from vz_hip import tp as tp_plan
+        eng = self.engine
+        T = int(images.shape[0])
+        mine = tp_plan.local_tiles(T, eng.tp_rank, eng.tp_size)
+        per = tp_plan.tiles_per_rank(T, eng.tp_size)
+        send = torch.zeros(per, self.arch.qf_queries, self.arch.hidden, dtype=torch.bfloat16, device=self.device)
+        if mine:
+            idx = torch.tensor(mine, device=images.device)
+            if text_embeddings is None:
+                text, ts = None, None
+            elif tile_sample is None:                    # one text block per tile
+                text, ts = text_embeddings.index_select(0, idx.to(text_embeddings.device)), None
+            else:                                        # one text block per sample + the tile -> sample map
+                text, ts = text_embeddings, [int(tile_sample[t]) for t in mine]
+            feats = self.get_model().get_vision_tower()(images.index_select(0, idx))
+            send[: len(mine)] = self.get_model().mm_projector(feats, text_embeddings=text, tile_sample=ts)
+        got = eng.all_gather(send).view(eng.tp_size * per, self.arch.qf_queries, self.arch.hidden)
+        return got.index_select(0, tp_plan.gathered_index(T, eng.tp_size).to(got.device))
 
     # a6 / a7 -------------------------------------------------------------------------------------
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,

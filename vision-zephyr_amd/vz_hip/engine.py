@@ -255,6 +255,21 @@ class Engine:
         dist.broadcast_object_list(box, src=0)
         B.check(self.lib.vz_comm_init(self.h, box[0]))
 
+    def init_comm_single_rank(self):
+        """self-test: give a tp_size == 1 engine a ONE-rank RCCL communicator; with vz_tune_set(7, 1) its all-reduce /
+        all-gather call sites then really go through RCCL (identity results) on a single GPU."""
+        assert self.tp_size == 1
+        buf = C.create_string_buffer(128)
+        B.check(self.lib.vz_comm_unique_id(buf))
+        B.check(self.lib.vz_comm_init(self.h, bytes(buf.raw)))
+
+    def all_gather(self, send: torch.Tensor) -> torch.Tensor:
+        """RCCL all-gather of one equally sized contiguous tensor per rank -> [tp_size, *send.shape] (rank order)."""
+        send = send.to(self.device).contiguous()
+        recv = torch.empty((self.tp_size,) + tuple(send.shape), dtype=send.dtype, device=self.device)
+        B.check(self.lib.vz_tp_all_gather(self.h, B.ptr(send), B.ptr(recv), send.numel() * send.element_size(), self._s()))
+        return recv
+
     def load_synthetic(self, seed: int = 0):
         """hash-generated weights, produced on the device (bit-identical to the CPU generator)."""
         self.load_weights(iter_state_dict(self.cfg, seed, device=self.device))

@@ -62,3 +62,21 @@ def vocab_range(vocab: int, rank: int, world: int) -> Tuple[int, int]:
 def allreduce_bytes_per_layer(cfg, tokens: int) -> int:
     """bf16 payload of the two all-reduces of one decoder layer (16.8 MB at S=2048)."""
     return 2 * tokens * cfg.hidden * 2
+
+
+# ---- tile data parallelism for CLIP + fusion + Q-Former (SURVEY.md section 8e, first row) ----
+def local_tiles(n_tiles: int, rank: int, world: int):
+    """tiles of a batch dealt round-robin: tile t lives on rank t mod world (5 tiles on 8 GPUs -> 5 GPUs busy)."""
+    return list(range(rank, n_tiles, world))
+
+
+def tiles_per_rank(n_tiles: int, world: int) -> int:
+    """slots per rank in the all-gather buffer (the ranks with fewer tiles zero-pad)."""
+    return (n_tiles + world - 1) // world
+
+
+def gathered_index(n_tiles: int, world: int) -> torch.Tensor:
+    """row of the flattened all-gather result [world * tiles_per_rank] that holds tile t: rank (t mod world), slot (t div world)."""
+    per = tiles_per_rank(n_tiles, world)
+    t = torch.arange(n_tiles)
+    return (t % world) * per + t // world
