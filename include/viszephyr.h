@@ -136,6 +136,9 @@ typedef struct vz_config {
     int max_text;         /* Lmax of the Q-Former text conditioning          */
     /* tensor parallelism over RCCL (1 = single GPU) */
     int tp_size, tp_rank;
+    /* mm_vision_select_feature (ref:vis_zephyr/model/vision_encoder/vision_encoder.py:66-73): 0 = 'patch' (drop CLS, 576 tokens per
+     * tile, the shipped config), 1 = 'cls_patch' (keep it: 577 tokens per tile into the fusion and the Q-Former) */
+    int clip_keep_cls;
 } vz_config;
 
 int vz_engine_create(const vz_config* cfg, vz_engine** out);

@@ -22,8 +22,8 @@ os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
 sys.dont_write_bytecode = True
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
-sys.path.insert(0, REF)                                   # `vis_zephyr` -> the reference
-sys.path.append(os.path.join(REPO, "vision-zephyr_amd"))  # `vz_hip` -> ours (synth only)
+_OURS = os.path.join(REPO, "vision-zephyr_amd")
+sys.path.append(_OURS)                                    # `vz_hip` -> ours (synth only)
 sys.path.append(REPO)
 
 import numpy as np
@@ -31,6 +31,11 @@ import torch
 
 from vz_hip import synth                                   # noqa: E402
 from oracle import vz_oracle as O                          # noqa: E402
+
+# `vis_zephyr` must resolve to the REFERENCE: it has no top-level __init__.py (a namespace package), and the drop-in mirror
+# under vision-zephyr_amd/ is a regular package that would win regardless of path order - take our directory off the path
+sys.path.remove(_OURS)
+sys.path.insert(0, REF)
 
 PINPOINTS = "[[336, 672], [672, 336], [336, 1008], [1008, 336]]"
 
@@ -210,11 +215,24 @@ def main():
     assert torch.equal(gen_ref, gen)
     fx["C.generate.ids"] = gen_ref.numpy().astype(np.int64)
 
+    # ---------------- case D: mm_vision_select_feature = 'cls_patch' (ref vision_encoder.py:66-73): 577 tokens per tile ----------------
+    tower.select_feature = "cls_patch"
+    try:
+        tiles_d = synth.synth_tiles(2, seed=8)
+        fused_ref_d = tower(tiles_d)
+        assert tuple(fused_ref_d.shape) == (2, cfg.clip_tokens, 5 * cfg.clip_hidden)
+        fused_d = O.clip_tower(cfg, sd, tiles_d, select_feature="cls_patch")
+        check("D.fused.cls_patch", fused_d, fused_ref_d)
+        te_d = te[:2]
+        check("D.encode_images.cls_patch", O.qformer(cfg, sd, fused_d, te_d), model.encode_images(tiles_d, te_ref[:2]))
+    finally:
+        tower.select_feature = "patch"
+
     meta = dict(llm_layers=args.llm_layers, seed=args.seed, report=report,
                 torch=torch.__version__, transformers=__import__("transformers").__version__,
                 note="outputs of the reference (fp32, CPU) on hash-generated weights; inputs regenerate from seeds "
                      "(A: tiles seed 1 n=3, ids seed 2 n=32 image_pos 5; B: tiles seeds 3 (n=2) / 4 (n=1), ids seeds 5/6; "
-                     "C: ids seed 7 n=9)")
+                     "C: ids seed 7 n=9; D: tiles seed 8 n=2 with the text of case A, select_feature cls_patch)")
     np.savez_compressed(os.path.join(args.out, f"pin_l{args.llm_layers}.npz"), **fx)
     with open(os.path.join(args.out, f"pin_l{args.llm_layers}.json"), "w") as f:
         json.dump(meta, f, indent=1)

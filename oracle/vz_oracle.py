@@ -165,9 +165,12 @@ def fusion(cfg, hidden_states: Sequence[torch.Tensor], P: Prec = FP32, select_fe
     return P.r(torch.cat(groups + [last], dim=-1))
 
 
-def clip_tower(cfg, sd, images, P: Prec = FP32):
-    """a8: CLIPVisionTower.forward for a 4-D batch -> [T,576,5*C]."""
-    return fusion(cfg, clip_hidden_states(cfg, sd, images, P), P)
+def clip_tower(cfg, sd, images, P: Prec = FP32, select_feature: Optional[str] = None):
+    """a8: CLIPVisionTower.forward for a 4-D batch -> [T,576,5*C] ('patch') or [T,577,5*C] ('cls_patch',
+    ref:vis_zephyr/model/vision_encoder/vision_encoder.py:66-73); default follows cfg.clip_keep_cls."""
+    if select_feature is None:
+        select_feature = "cls_patch" if getattr(cfg, "clip_keep_cls", False) else "patch"
+    return fusion(cfg, clip_hidden_states(cfg, sd, images, P), P, select_feature)
 
 
 # ================================================================================================

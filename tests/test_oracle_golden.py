@@ -51,6 +51,19 @@ def test_case_a_all_stages(env):
     assert np.allclose(glog[0, :, ::37].numpy(), g["A.generate.step_logits.sub"], atol=3e-4)
 
 
+def test_case_d_cls_patch(env):
+    """mm_vision_select_feature = 'cls_patch' (ref vision_encoder.py:66-73): 577 tokens per tile."""
+    cfg, sd, O, S, g = env
+    tiles = S.synth_tiles(2, seed=8)
+    ids = S.synth_ids(32, cfg.vocab, image_pos=5, seed=2)
+    te = O.embed_tokens(sd, ids[ids != -200], O.FP32).unsqueeze(0).expand(2, -1, -1)
+    fused = O.clip_tower(cfg, sd, tiles, select_feature="cls_patch")
+    _chk(g, "D.fused.cls_patch", fused)
+    _chk(g, "D.encode_images.cls_patch", O.qformer(cfg, sd, fused, te))
+    with pytest.raises(ValueError):
+        O.fusion(cfg, [fused] * 25, select_feature="cls")
+
+
 def test_case_c_text_only_generate(env):
     cfg, sd, O, S, g = env
     ids = S.synth_ids(9, cfg.vocab, image_pos=-1, seed=7).unsqueeze(0)

@@ -352,3 +352,35 @@ def test_sampling_is_seeded_and_follows_the_logits(env):
     greedy = model.generate(input_ids=ids, do_sample=False, max_new_tokens=4, eos_token_id=None)
     cold = model.generate(input_ids=ids, do_sample=True, temperature=1e-4, max_new_tokens=4, eos_token_id=None)
     assert cold.tolist() == greedy.tolist()
+
+
+def test_cls_patch_feature_selection(env):
+    """mm_vision_select_feature = 'cls_patch' (ref vision_encoder.py:66-73): the class token stays in, 577 visual tokens per
+    tile flow through the fusion and into the Q-Former's cross-attention.  Golden case D + the bf16 band."""
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    O, sd, synth = env["O"], env["sd"], env["synth"]
+    cfg = synth.ArchConfig(n_layers=1, clip_keep_cls=True)
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=1,
+                         num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab,
+                         rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, sliding_window=cfg.sliding_window,
+                         eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    hf.mm_hidden_size = 5120
+    hf.mm_vision_select_feature = "cls_patch"
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=256, max_tiles=2, max_text=64)
+    assert model.arch.clip_keep_cls and model.arch.vision_tokens == 577
+    tiles = synth.synth_tiles(2, seed=8)
+    ids = synth.synth_ids(32, cfg.vocab, image_pos=5, seed=2)
+    te = O.embed_tokens(sd, ids[ids != -200], O.BF16).unsqueeze(0).expand(2, -1, -1)
+    fused = model.get_vision_tower()(tiles.to(model.device).bfloat16())
+    assert tuple(fused.shape) == (2, 577, 5120)
+    band("fused cls_patch", fused, O.clip_tower(cfg, sd, tiles, O.BF16), O.clip_tower(cfg, sd, tiles, O.FP32))
+    _gold_check(env, "D.fused.cls_patch", fused, 5e-2, 1.5e-2)
+    feats = O.clip_tower(cfg, sd, tiles, O.BF16)                      # same features into both sides
+    out = model.engine.qformer(feats.bfloat16(), te.bfloat16()[:1].contiguous(), [0, 0])
+    band("qformer cls_patch", out, O.qformer(cfg, sd, feats, te, O.BF16), O.qformer(cfg, sd, feats, te, O.FP32))
+    enc = model.encode_images(tiles.to(model.device).bfloat16(), te.bfloat16().to(model.device))
+    _gold_check(env, "D.encode_images.cls_patch", enc, 1e-1, 3e-2)
+    del model
+    torch.cuda.empty_cache()

@@ -201,21 +201,23 @@ __global__ __launch_bounds__(256) void clip_assemble_kernel(const bf16_t* __rest
 // ------------------------------------------------------------------------------------------------
 // Multi-layer fusion (ref:vis_zephyr/model/vision_encoder/vision_encoder.py:58-78,
 // ref:vis_zephyr/model/gating_fusion/gating_fusion.py:22-50): hidden states first_layer..last,
-// drop CLS, `groups` means of `per_group` consecutive layers + the last layer, channel-concat.
+// drop (`skip` = 1, 'patch') or keep (`skip` = 0, 'cls_patch') CLS, `groups` means of `per_group` consecutive layers + the last
+// layer, channel-concat.
 // hs_base: [(layers), T, tokens, C] with `layer_stride` elements between layers.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fusion_kernel(const bf16_t* __restrict__ hs_base, long layer_stride, int first_layer,
-                                                     int groups, int per_group, int T, int tokens, int C,
+                                                     int groups, int per_group, int T, int tokens, int C, int skip,
                                                      bf16_t* __restrict__ out) {
     const int chunks_per_row = C / 8;
-    const long total = (long)T * (tokens - 1) * (groups + 1) * chunks_per_row;
+    const int keep = tokens - skip;
+    const long total = (long)T * keep * (groups + 1) * chunks_per_row;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % chunks_per_row);
         long r = i / chunks_per_row;
         const int gidx = (int)(r % (groups + 1));
         r /= (groups + 1);
-        const int ptk = (int)(r % (tokens - 1)), t = (int)(r / (tokens - 1));
-        const size_t off = ((size_t)t * tokens + 1 + ptk) * C + ch * 8;
+        const int ptk = (int)(r % keep), t = (int)(r / keep);
+        const size_t off = ((size_t)t * tokens + skip + ptk) * C + ch * 8;
         u16x8 o;
         if (gidx == groups) {
             o = *(const u16x8*)(hs_base + (size_t)(first_layer + groups * per_group) * layer_stride + off);
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void fusion_kernel(const bf16_t* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = f32_to_bf16(acc[j] / cnt);
         }
-        *(u16x8*)(out + ((size_t)t * (tokens - 1) + ptk) * ((size_t)(groups + 1) * C) + (size_t)gidx * C + ch * 8) = o;
+        *(u16x8*)(out + ((size_t)t * keep + ptk) * ((size_t)(groups + 1) * C) + (size_t)gidx * C + ch * 8) = o;
     }
 }
 
@@ -356,12 +358,12 @@ int vz_launch_clip_assemble(const bf16_t* patch_out, const bf16_t* cls, const bf
 }
 
 int vz_launch_fusion(const bf16_t* hs_base, long layer_stride, int first_layer, int groups, int per_group, int T, int tokens,
-                     int C, bf16_t* out, hipStream_t s) {
-    const long total = (long)T * (tokens - 1) * (groups + 1) * (C / 8);
+                     int C, int skip, bf16_t* out, hipStream_t s) {
+    const long total = (long)T * (tokens - skip) * (groups + 1) * (C / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(fusion_kernel, dim3((int)blocks), dim3(256), 0, s, hs_base, layer_stride, first_layer, groups, per_group,
-                       T, tokens, C, out);
+                       T, tokens, C, skip, out);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }

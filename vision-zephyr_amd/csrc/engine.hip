@@ -37,7 +37,7 @@ void vz_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vz_last_error(void) { return g_err; }
-extern "C" int vz_abi_version(void) { return 1; }
+extern "C" int vz_abi_version(void) { return 2; }
 extern "C" const char* vz_target_arch(void) { return "gfx950"; }
 
 // ------------------------------------------------------------------------------------------------
@@ -430,7 +430,7 @@ extern "C" int vz_clip_fused_features(vz_engine* e, const void* d_images, int T,
     {
         ProfScope ps(e, K_OTHER, s);
         const int first = L - c.fusion_groups * c.fusion_layers_per_group;
-        RC(vz_launch_fusion(hs, (long)hs_layer, first, c.fusion_groups, c.fusion_layers_per_group, T, tokens, C, (bf16_t*)d_out, s));
+        RC(vz_launch_fusion(hs, (long)hs_layer, first, c.fusion_groups, c.fusion_layers_per_group, T, tokens, C, c.clip_keep_cls ? 0 : 1, (bf16_t*)d_out, s));
     }
     return rc;
 }
@@ -460,7 +460,8 @@ extern "C" int vz_qformer(vz_engine* e, const void* d_feats, int T, const void* 
     VZ_CHECK_ARG(Lmax >= 0 && Lmax <= c.max_text, "qformer: Lmax=%d outside [0,%d]", Lmax, c.max_text);
     VZ_CHECK_ARG(n_samples >= 1 && n_samples <= T && h_tile_sample && (Lmax == 0 || d_text), "qformer: bad sample map");
     for (int t = 0; t < T; ++t) VZ_CHECK_ARG(h_tile_sample[t] >= 0 && h_tile_sample[t] < n_samples, "qformer: tile_sample[%d] out of range", t);
-    const int H = c.hidden, NQ = c.qf_queries, KD = c.qf_kv_dim, P = (c.clip_image / c.clip_patch) * (c.clip_image / c.clip_patch);
+    const int H = c.hidden, NQ = c.qf_queries, KD = c.qf_kv_dim;
+    const int P = (c.clip_image / c.clip_patch) * (c.clip_image / c.clip_patch) + (c.clip_keep_cls ? 1 : 0);   // visual tokens per tile
     const int N0 = NQ + Lmax, FF = 2 * H;
     const size_t R = (size_t)T * NQ;  // query rows in flight after block 0's self-attention
     size_t need;

@@ -160,7 +160,7 @@ int vz_launch_im2col(const bf16_t* img, int T, int image, int patch, int kpad, b
 int vz_launch_clip_assemble(const bf16_t* patch_out, const bf16_t* cls, const bf16_t* pos, int T, int tokens, int C,
                             bf16_t* out, hipStream_t s);
 int vz_launch_fusion(const bf16_t* hs_base, long layer_stride, int first_layer, int groups, int per_group, int T,
-                     int tokens, int C, bf16_t* out, hipStream_t s);
+                     int tokens, int C, int skip, bf16_t* out, hipStream_t s);
 int vz_launch_argmax(const float* logits, int rows, int cols, int* ids, int* pos, int* slot, int* len, int* out_ids,
                      int out_stride, const int* step, hipStream_t s);
 // set dynamic-LDS limits of every kernel up front (never inside a stream capture)

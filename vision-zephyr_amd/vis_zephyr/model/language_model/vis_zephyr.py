@@ -45,7 +45,9 @@ def arch_from_config(config) -> ArchConfig:
     return ArchConfig(hidden=hidden, inter=g("intermediate_size", 14336), n_layers=g("num_hidden_layers", 32),
                       n_heads=heads, n_kv_heads=g("num_key_value_heads", 8), head_dim=g("head_dim", hidden // heads),
                       vocab=g("vocab_size", 32000), rms_eps=g("rms_norm_eps", 1e-5),
-                      rope_theta=float(g("rope_theta", 10000.0)), sliding_window=g("sliding_window", 4096))
+                      rope_theta=float(g("rope_theta", 10000.0)), sliding_window=g("sliding_window", 4096),
+                      # 'cls_patch' keeps the class token: 577 visual tokens per tile (ref vision_encoder.py:66-73)
+                      clip_keep_cls=g("mm_vision_select_feature", "patch") == "cls_patch")
 
 
 class _Embedding:

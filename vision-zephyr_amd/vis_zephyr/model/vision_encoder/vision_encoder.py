@@ -27,11 +27,11 @@ class CLIPVisionTower:
                                  f"integers, but got: {raw}")
         else:
             self.select_layers = [-2]
-        if self.select_feature not in ("patch",):
-            # 'cls_patch' keeps 577 tokens per tile; the engine's fusion kernel drops CLS (the shipped config)
-            if self.select_feature == "cls_patch":
-                raise NotImplementedError("mm_vision_select_feature='cls_patch' is not built in the MI355X engine")
+        if self.select_feature not in ("patch", "cls_patch"):      # ref :72-73 raises at the first forward; same exception type
             raise ValueError(f"Unknown feature selection strategy: {self.select_feature}")
+        if owner is not None and (self.select_feature == "cls_patch") != bool(owner.arch.clip_keep_cls):
+            raise ValueError("mm_vision_select_feature changed after the engine was built: the number of visual tokens per "
+                             "tile (576 'patch' / 577 'cls_patch') is fixed at construction")
         self._owner = owner            # VisZephyrForCausalLM holding the engine
         self.image_processor = None
         if not delay_load:

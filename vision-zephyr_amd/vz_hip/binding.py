@@ -31,7 +31,7 @@ class VzConfig(C.Structure):
         ("qf_eps", C.c_float),
         ("fusion_groups", C.c_int), ("fusion_layers_per_group", C.c_int),
         ("max_batch", C.c_int), ("max_ctx", C.c_int), ("max_tiles", C.c_int), ("max_text", C.c_int),
-        ("tp_size", C.c_int), ("tp_rank", C.c_int),
+        ("tp_size", C.c_int), ("tp_rank", C.c_int), ("clip_keep_cls", C.c_int),
     ]
 
 

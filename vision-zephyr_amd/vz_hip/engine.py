@@ -57,7 +57,8 @@ class Engine:
             clip_patch=cfg.clip_patch, clip_eps=cfg.clip_eps, qf_queries=cfg.qf_queries, qf_blocks=cfg.qf_blocks,
             qf_heads=cfg.qf_heads, qf_kv_dim=cfg.qf_kv_dim, qf_eps=cfg.qf_eps, fusion_groups=cfg.fusion_groups,
             fusion_layers_per_group=cfg.fusion_layers_per_group, max_batch=max_batch, max_ctx=max_ctx,
-            max_tiles=max_tiles, max_text=max_text, tp_size=tp_size, tp_rank=tp_rank)
+            max_tiles=max_tiles, max_text=max_text, tp_size=tp_size, tp_rank=tp_rank,
+            clip_keep_cls=int(cfg.clip_keep_cls))
         h = C.c_void_p()
         B.check(self.lib.vz_engine_create(C.byref(c), C.byref(h)))
         self.h = h
@@ -298,7 +299,7 @@ class Engine:
                              f"({cfg.clip_image}*{cfg.clip_image}).")
         x = images.to(self.device, torch.bfloat16).contiguous()
         T = x.shape[0]
-        out = torch.empty(T, cfg.clip_patches, (cfg.fusion_groups + 1) * cfg.clip_hidden, dtype=torch.bfloat16,
+        out = torch.empty(T, cfg.vision_tokens, (cfg.fusion_groups + 1) * cfg.clip_hidden, dtype=torch.bfloat16,
                           device=self.device)
         hid = None
         if return_hidden:

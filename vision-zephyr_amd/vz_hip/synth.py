@@ -120,6 +120,8 @@ class ArchConfig:
     # fusion (ref:vis_zephyr/model/vision_encoder/vision_encoder.py:63-64)
     fusion_groups: int = 4
     fusion_layers_per_group: int = 5
+    # mm_vision_select_feature == 'cls_patch' (ref:vis_zephyr/model/vision_encoder/vision_encoder.py:66-73): CLS stays in
+    clip_keep_cls: bool = False
 
     @property
     def clip_tokens(self) -> int:
@@ -128,6 +130,11 @@ class ArchConfig:
     @property
     def clip_patches(self) -> int:
         return (self.clip_image // self.clip_patch) ** 2
+
+    @property
+    def vision_tokens(self) -> int:
+        """tokens per tile that leave the tower: 576 ('patch') or 577 ('cls_patch')"""
+        return self.clip_patches + (1 if self.clip_keep_cls else 0)
 
     @property
     def qf_ffn(self) -> int:
