@@ -149,6 +149,10 @@ int vz_engine_destroy(vz_engine* e);
 int vz_engine_set_weight(vz_engine* e, const char* name, const void* d_ptr, int dtype, long n_elems);
 /* check that every weight the configuration needs has been registered */
 int vz_engine_finalize(vz_engine* e);
+/* change the vocabulary of a live engine (tokens added to the tokenizer: ref:vis_zephyr/model/builder.py:141-153 grows
+ * embed_tokens / lm_head by <im_patch>).  The caller then registers the new "llm.embed" / "llm.lm_head" tables and
+ * finalizes again.  tp_size == 1 only. */
+int vz_engine_resize_vocab(vz_engine* e, int new_vocab);
 /* Tensor parallelism (vz_config.tp_size > 1): one process per GPU; q/k/v/gate/up column-parallel,
  * o/down row-parallel with an RCCL all-reduce of [B,S,hidden] bf16 after each (2 per layer), lm_head vocab-parallel with
  * an all-gather of the fp32 logits; the KV cache is sharded by KV head.  CLIP / Q-Former weights are replicated.

@@ -384,3 +384,26 @@ def test_cls_patch_feature_selection(env):
     _gold_check(env, "D.encode_images.cls_patch", enc, 1e-1, 3e-2)
     del model
     torch.cuda.empty_cache()
+
+
+def test_resize_token_embeddings_live(env):
+    """ref builder.py:141-153 adds <im_patch> and calls model.resize_token_embeddings(32001): the live engine grows its
+    embedding / lm_head tables (new row = mean of the old rows), old logits stay bit-identical, the new id embeds to the mean."""
+    model, cfg = env["model"], env["cfg"]
+    eng = model.engine
+    ids = env["synth"].synth_ids(24, cfg.vocab, image_pos=-1, seed=11).unsqueeze(0).to(model.device)
+    before = model(input_ids=ids).logits
+    mean_row = eng.w["llm.embed"].float().mean(0).bfloat16()
+    try:
+        model.resize_token_embeddings(cfg.vocab + 1)
+        assert model.config.vocab_size == cfg.vocab + 1 and eng.cfg.vocab == cfg.vocab + 1
+        after = model(input_ids=ids).logits
+        assert after.shape[-1] == cfg.vocab + 1
+        assert torch.equal(after[..., :cfg.vocab], before)
+        emb = model.get_model().embed_tokens(torch.tensor([cfg.vocab], device=model.device))
+        assert torch.equal(emb[0], mean_row)
+        out = model.generate(input_ids=ids, do_sample=False, max_new_tokens=4, eos_token_id=None, pad_token_id=2)
+        assert out.shape == (1, 4) and int(out.max()) <= cfg.vocab
+    finally:
+        model.resize_token_embeddings(cfg.vocab)
+    assert torch.equal(model(input_ids=ids).logits, before)

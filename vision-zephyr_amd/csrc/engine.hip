@@ -311,6 +311,22 @@ extern "C" int vz_engine_set_weight(vz_engine* e, const char* name, const void* 
     return VZ_OK;
 }
 
+extern "C" int vz_engine_resize_vocab(vz_engine* e, int new_vocab) {
+    VZ_CHECK_ARG(e && new_vocab > 0, "resize_vocab: bad argument");
+    VZ_CHECK_ARG(e->tp == 1, "resize_vocab: not available on a tensor-parallel engine (rebuild it at the new vocabulary)");
+    if (new_vocab == e->c.vocab) return VZ_OK;
+    VZ_CHECK_HIP(hipDeviceSynchronize());
+    if (e->dec_graph) { (void)hipGraphExecDestroy(e->dec_graph); e->dec_graph = nullptr; }     // it holds the old logits width
+    if (e->d_logits) { VZ_CHECK_HIP(hipFree(e->d_logits)); e->d_logits = nullptr; }
+    e->c.vocab = new_vocab;
+    e->Vp = new_vocab;
+    VZ_CHECK_HIP(hipMalloc((void**)&e->d_logits, (size_t)e->c.max_batch * e->Vp * sizeof(float)));
+    e->w.erase("llm.embed");
+    e->w.erase("llm.lm_head");
+    e->finalized = false;
+    return VZ_OK;
+}
+
 static int kpad_patch(const vz_config& c) { return (int)align_up((size_t)3 * c.clip_patch * c.clip_patch, 64); }
 
 extern "C" int vz_engine_finalize(vz_engine* e) {

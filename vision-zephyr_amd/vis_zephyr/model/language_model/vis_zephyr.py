@@ -149,10 +149,12 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         """ref:vis_zephyr/model/builder.py:141-153 grows embed_tokens / lm_head by `<im_patch>`; new rows are
         the mean of the old ones (HF mean-resizing)."""
         old = self.arch.vocab
-        if n == old:
+        if n is None or n == old:
             return self.model.embed_tokens
-        raise NotImplementedError("resize_token_embeddings: build the engine with config.vocab_size = len(tokenizer) "
-                                  "and load the resized tables (vz_hip.weights.resize_vocab)")
+        self.engine.resize_vocab(int(n))
+        self.arch = self.engine.cfg
+        self.config.vocab_size = int(n)
+        return self.model.embed_tokens
 
     # ---- forward (a2) -----------------------------------------------------------------------------
     @torch.no_grad()

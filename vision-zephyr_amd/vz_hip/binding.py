@@ -64,6 +64,7 @@ SYMBOLS = {
     "vz_llm_decode_begin": (_I, [_P, _I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
     "vz_tune_set": (_I, [_I, _I]),
+    "vz_engine_resize_vocab": (_I, [_P, _I]),
     "vz_tp_all_gather": (_I, [_P, _P, _P, C.c_size_t, _P]),
     "vz_prof_enable": (_I, [_P, _I, _I]),
     "vz_prof_read": (_I, [_P, C.POINTER(C.c_long), C.POINTER(C.c_double)]),

@@ -256,6 +256,32 @@ class Engine:
         dist.broadcast_object_list(box, src=0)
         B.check(self.lib.vz_comm_init(self.h, box[0]))
 
+    def resize_vocab(self, n: int):
+        """grow (new rows = mean of the old ones, as vz_hip.weights.resize_vocab does at load time) or shrink the
+        embedding and lm_head tables of a live engine (HF `resize_token_embeddings`; ref builder.py:141-153)."""
+        import dataclasses
+        if self.tp_size != 1:
+            raise NotImplementedError("resize_vocab on a tensor-parallel engine: rebuild it at the new vocabulary")
+        old = self.cfg.vocab
+        if n == old:
+            return
+        tables = {}
+        for name in ("llm.embed", "llm.lm_head"):
+            t = self.w[name]
+            if n > old:
+                extra = t.float().mean(0, keepdim=True).to(t.dtype).expand(n - old, -1)
+                tables[name] = torch.cat([t, extra], 0).contiguous()
+            else:
+                tables[name] = t[:n].contiguous()
+        torch.cuda.synchronize(self.device)
+        B.check(self.lib.vz_engine_resize_vocab(self.h, n))
+        self.cfg = dataclasses.replace(self.cfg, vocab=n)
+        self.vp = n
+        for name, t in tables.items():
+            self.w[name] = t
+            self._registered.discard(name)
+        self.finalize()
+
     def init_comm_single_rank(self):
         """self-test: give a tp_size == 1 engine a ONE-rank RCCL communicator; with vz_tune_set(7, 1) its all-reduce /
         all-gather call sites then really go through RCCL (identity results) on a single GPU."""
