@@ -63,6 +63,12 @@ const char* vz_target_arch(void);
 int vz_op_linear(const void* d_A, int lda, const void* d_W, int ldw, void* d_C, int ldc,
                  int M, int N, int K, const float* d_bias, const void* d_residual, int ldr,
                  int act, int out_fp32, vz_stream stream);
+/* W8A16 weight stream for M <= 8 (decode): W as OCP e4m3 rows [N, ldw bytes] + one fp32 power-of-two scale per row
+ * (vz_hip/quant.py: 2^e * fp8 is exactly a bf16 number, so the bf16 GEMMs of the prefill run on the same weights).
+ * Same epilogues as vz_op_linear; K % 1024 == 0; d_norm_w != NULL fuses the RMSNorm of x into the staging. */
+int vz_op_linear_fp8(const void* d_A, int lda, const void* d_W8, int ldw, const float* d_wscale, void* d_C, int ldc,
+                     int M, int N, int K, const float* d_bias, const void* d_residual, int ldr, int act, int out_fp32,
+                     const float* d_norm_w, float norm_eps, vz_stream stream);
 /* same contract, forcing one implementation (tests): impl 0 = MFMA tile GEMM, 1 = GEMV */
 int vz_op_linear_impl(int impl, const void* d_A, int lda, const void* d_W, int ldw, void* d_C, int ldc,
                       int M, int N, int K, const float* d_bias, const void* d_residual, int ldr,
@@ -139,13 +145,17 @@ typedef struct vz_config {
     /* mm_vision_select_feature (ref:vis_zephyr/model/vision_encoder/vision_encoder.py:66-73): 0 = 'patch' (drop CLS, 576 tokens per
      * tile, the shipped config), 1 = 'cls_patch' (keep it: 577 tokens per tile into the fusion and the Q-Former) */
     int clip_keep_cls;
+    /* 1 = the decode-side linears of Zephyr (q|k|v, o, gate|up, down, lm_head at M <= 8) stream e4m3 copies of the weights
+     * ("<name>8" u8 + "<name>s" fp32 row scales, registered beside the bf16 tensors); the bf16 tensors must then hold the
+     * dequantised values so that prefill and decode run the same model (vz_hip/quant.py, SURVEY config 5) */
+    int weight_fp8;
 } vz_config;
 
 int vz_engine_create(const vz_config* cfg, vz_engine** out);
 int vz_engine_destroy(vz_engine* e);
 
 /* Register one weight under its engine name (see vz_hip/weights.py for the packing from the
- * reference's state-dict keys).  dtype: 0 = bf16, 1 = fp32.  The pointer is borrowed until destroy. */
+ * reference's state-dict keys).  dtype: 0 = bf16, 1 = fp32, 2 = u8 (e4m3 bytes).  The pointer is borrowed until destroy. */
 int vz_engine_set_weight(vz_engine* e, const char* name, const void* d_ptr, int dtype, long n_elems);
 /* check that every weight the configuration needs has been registered */
 int vz_engine_finalize(vz_engine* e);

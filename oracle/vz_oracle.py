@@ -229,6 +229,32 @@ def encode_images(cfg, sd, images, text_embeddings, P: Prec = FP32):
 
 
 # ================================================================================================
+# W8A16 weights (SURVEY config 5): CPU restatement of vz_hip/quant.py, applied to the reference-named state dict
+# ================================================================================================
+_FP8_KEYS = ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+             "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight")
+
+
+def fake_quantize_rows(w: torch.Tensor) -> torch.Tensor:
+    """one power-of-two scale per output row, weights rounded to OCP e4m3 (RNE): w -> 2^e * e4m3(w * 2^-e), e = ceil(log2(amax/448))."""
+    w = w.float()
+    amax = w.abs().amax(dim=1)
+    e = torch.where(amax > 0, torch.ceil(torch.log2(torch.clamp(amax, min=1e-30) / 448.0)), torch.zeros_like(amax))
+    q = (w * torch.exp2(-e).unsqueeze(1)).to(torch.float8_e4m3fn).float()
+    return q * torch.exp2(e).unsqueeze(1)
+
+
+def quantize_state_dict(sd):
+    """the model the weight_fp8 engine computes with: every Zephyr linear + lm_head row-quantised (rows are independent, so
+    quantising q/k/v or gate/up before the engine stacks them gives the same bytes); embeddings, norms, CLIP, Q-Former untouched."""
+    out = dict(sd)
+    for k, v in sd.items():
+        if k == "lm_head.weight" or (k.startswith("model.layers.") and k.endswith(_FP8_KEYS)):
+            out[k] = fake_quantize_rows(v)
+    return out
+
+
+# ================================================================================================
 # a6/a7: embedding splice  (ref:vis_zephyr/model/vis_zephyr_arch.py:129-333,396-530)
 # ================================================================================================
 def embed_tokens(sd, ids: torch.Tensor, P: Prec):

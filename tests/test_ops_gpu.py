@@ -436,3 +436,58 @@ def test_gemm_splitk_small_m(B, M, N, K, act):
     check_close(f"gemm split-K vs single pass {M}x{N}x{K}", out, plain.float(), 8e-3, 5e-4)
     o32 = B.linear(x, w, out_fp32=True, impl=0)
     check_close(f"gemm split-K fp32 {M}x{N}x{K}", o32, _ref_linear(x, w, None, None, 0), 1e-4, 1e-4)
+
+
+# ---- W8A16 weight stream (SURVEY config 5): e4m3 rows + one power-of-two scale per row ----
+@pytest.mark.parametrize("M,N,K,act", [(1, 6144, 4096, 0), (1, 4096, 14336, 0), (1, 28672, 4096, 3), (2, 4096, 4096, 0),
+                                       (4, 1024, 4096, 0), (8, 2048, 2048, 3), (1, 32001, 4096, 0), (3, 257, 1024, 0)])
+def test_gemv_fp8_weights(B, M, N, K, act):
+    """The fp8 GEMV must equal the dot product with the DEQUANTISED weights (2^e * e4m3, exact in bf16) to fp32
+    accumulation accuracy, through every epilogue; and the dequantised bf16 weights through the bf16 GEMV must give the
+    same result (prefill and decode run one model)."""
+    from vz_hip import quant
+    x = _rand((M, K), 1.0, 90).bfloat16()
+    w = _rand((N, K), 0.03, 91)
+    w[5] *= 37.0                                   # rows of very different magnitude: per-row scales matter
+    w[7] = 0.0                                     # an all-zero row quantises to scale 1, bytes 0
+    w8, scale = quant.quantize_rows(w)
+    wq = quant.dequantize_rows(w8, scale)
+    assert torch.equal(wq.bfloat16().float(), wq)  # exactly representable in bf16
+    assert float((wq - w).abs().max() / w.abs().max()) < 0.07
+    n_out = N // 2 if act == 3 else N
+    res = _rand((M, n_out), 1.0, 92).bfloat16()
+    bias = None if act == 3 else _rand((N,), 0.3, 93)
+    out32 = B.linear_fp8(x, w8, scale, act=act, out_fp32=True)
+    check_close(f"gemv fp8 fp32 {M}x{N}x{K} act{act}", out32, _ref_linear(x, wq, None, None, act), 1e-4, 1e-4)
+    out = B.linear_fp8(x, w8, scale, bias=bias, residual=res, act=act)
+    check_close(f"gemv fp8 {M}x{N}x{K} act{act}", out, _ref_linear(x, wq, bias, res, act), BF16_MAX, BF16_L2)
+    same = B.linear(x, wq.bfloat16(), bias=bias, residual=res, act=act, impl=1)
+    # identical products and the same fp32 accumulation order per lane would make these bit-equal; the lane -> k mapping
+    # differs (16 vs 8 weights per lane), so allow fp32 re-association: at most one bf16 step on a handful of outputs
+    assert float((out.float() - same.float()).abs().max()) <= 2 ** -7 * float(same.float().abs().max()) + 1e-6
+
+
+def test_gemv_fp8_fused_rmsnorm(B):
+    from vz_hip import quant
+    K, N = 4096, 6144
+    x = _rand((2, K), 3.0, 94).bfloat16()
+    nw = _rand((K,), 0.2, 95) + 1.0
+    w8, scale = quant.quantize_rows(_rand((N, K), 0.02, 96))
+    wq = quant.dequantize_rows(w8, scale)
+    xf = bf16r(x).double()
+    xn = (nw.double() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))).float().bfloat16()
+    out = B.linear_fp8(x, w8, scale, out_fp32=True, norm_w=nw, norm_eps=1e-5)
+    ref = _ref_linear(xn, wq, None, None, 0)
+    # the fused norm rounds x to bf16 like the stand-alone kernel; a different rounding of a few x entries moves the
+    # sum by ~2^-9 relative
+    check_close("gemv fp8 fused rmsnorm", out, ref, 2e-2, 3e-3)
+
+
+def test_gemv_fp8_rejects_bad_arguments(B):
+    from vz_hip import quant
+    w8, scale = quant.quantize_rows(_rand((64, 1536), 0.02, 97))
+    with pytest.raises(ValueError):
+        B.linear_fp8(_rand((1, 1536), 1.0, 98).bfloat16(), w8, scale)        # K not a multiple of 1024
+    w8, scale = quant.quantize_rows(_rand((64, 2048), 0.02, 97))
+    with pytest.raises(ValueError):
+        B.linear_fp8(_rand((9, 2048), 1.0, 98).bfloat16(), w8, scale)        # M > 8: the fp8 stream is a GEMV

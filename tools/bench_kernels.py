@@ -61,6 +61,37 @@ def bench_gemv():
     return res
 
 
+def bench_gemv_fp8():
+    """W8A16 weight stream: e4m3 rows + per-row scale, same shapes as the bf16 decode GEMVs; bytes = N*K (1 per weight)."""
+    from vz_hip import quant
+    import ctypes as C
+    shapes = [("qkv+norm", 6144, 4096, 0), ("o", 4096, 4096, 0), ("gate-up swiglu", 28672, 4096, 3), ("down", 4096, 14336, 0),
+              ("lm_head fp32", 32000, 4096, 0)]
+    for name, N, K, act in shapes:
+        pool = max(2, int(0.8e9 // (N * K)))
+        ws = []
+        for _ in range(pool):
+            w8, sc = quant.quantize_rows(torch.randn(N, K, device=dev) * 0.02)
+            ws.append((w8, sc))
+        x = torch.randn(1, K, device=dev).bfloat16()
+        out32 = "fp32" in name
+        n_out = N // 2 if act == 3 else N
+        out = torch.empty(1, n_out, dtype=torch.float32 if out32 else torch.bfloat16, device=dev)
+        st = B.stream_ptr()
+        fn = B.lib().vz_op_linear_fp8
+        argl = [(B.ptr(x), K, B.ptr(w8), K, B.ptr(sc), B.ptr(out), n_out, 1, N, K, None, None, 0, act, int(out32), None, C.c_float(0.0), st)
+                for w8, sc in ws]
+        rows = {}
+        for rnd in range(3):
+            for v in (0, 1):
+                B.check(B.lib().vz_tune_set(0, v))
+                rows.setdefault(v, []).append(timed(lambda i: fn(*argl[i % pool]), 6 * pool))
+        B.check(B.lib().vz_tune_set(0, 0))
+        mb = N * K / 1e6
+        print(f"gemv fp8 {name:16s} {mb:7.1f} MB: " + "  ".join(f"{'R2U8' if v == 0 else 'R4U4'}: {min(t):6.1f}us {mb / min(t):5.2f}TB/s" for v, t in rows.items()), flush=True)
+        del ws
+
+
 def bench_gemv_resident():
     """Does a GEMV run faster when its weights sit in the 256 MiB Infinity Cache (read by the previous kernel) than from
     HBM?  Same weights every launch (resident) vs a pool larger than the cache (streamed), per shape."""
@@ -176,6 +207,8 @@ if __name__ == "__main__":
         bench_gemv()
     if what in ("gemm", "all"):
         bench_gemm()
+    if what == "gemv8":
+        bench_gemv_fp8()
     if what == "gemvres":
         bench_gemv_resident()
     if what == "gemmsq":

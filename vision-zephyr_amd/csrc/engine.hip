@@ -37,7 +37,7 @@ void vz_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vz_last_error(void) { return g_err; }
-extern "C" int vz_abi_version(void) { return 2; }
+extern "C" int vz_abi_version(void) { return 3; }
 extern "C" const char* vz_target_arch(void) { return "gfx950"; }
 
 // ------------------------------------------------------------------------------------------------
@@ -55,6 +55,14 @@ static LinearArgs mk_linear(const void* A, int lda, const void* W, int ldw, void
 extern "C" int vz_op_linear(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                             const float* bias, const void* residual, int ldr, int act, int out_fp32, vz_stream s) {
     return vz_launch_linear(mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, act, out_fp32), (hipStream_t)s);
+}
+extern "C" int vz_op_linear_fp8(const void* A, int lda, const void* W8, int ldw, const float* wscale, void* C, int ldc, int M, int N,
+                                int K, const float* bias, const void* residual, int ldr, int act, int out_fp32,
+                                const float* norm_w, float norm_eps, vz_stream s) {
+    VZ_CHECK_ARG(W8 && wscale, "linear_fp8: null weights / scales");
+    LinearArgs a = mk_linear(A, lda, (const void*)W8, ldw, C, ldc, M, N, K, bias, residual, ldr, act, out_fp32);
+    a.W8 = (const unsigned char*)W8; a.wscale = wscale; a.norm_w = norm_w; a.norm_eps = norm_eps;
+    return vz_launch_gemv(a, (hipStream_t)s);
 }
 extern "C" int vz_op_linear_impl(int impl, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N,
                                  int K, const float* bias, const void* residual, int ldr, int act, int out_fp32,
@@ -167,6 +175,9 @@ static const void* W_(vz_engine* e, const std::string& name, int dtype, long n, 
 }
 #define WB(name, n) ((const bf16_t*)W_(e, name, 0, (long)(n), &rc))
 #define WF(name, n) ((const float*)W_(e, name, 1, (long)(n), &rc))
+// e4m3 copy + row scales of a decode-side weight (nullptr unless the engine was created with weight_fp8)
+#define W8(name, n) (e->c.weight_fp8 ? (const unsigned char*)W_(e, name, 2, (long)(n), &rc) : (const unsigned char*)nullptr)
+#define WS(name, n) (e->c.weight_fp8 ? (const float*)W_(e, name, 1, (long)(n), &rc) : (const float*)nullptr)
 #define RC(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
 struct ProfScope {
@@ -201,9 +212,13 @@ struct ProfScope {
 
 static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M,
                   int N, int K, const float* bias, const bf16_t* res, int ldr, int act, int out_fp32, hipStream_t s,
-                  const float* norm_w = nullptr, float norm_eps = 0.f) {
+                  const float* norm_w = nullptr, float norm_eps = 0.f, const unsigned char* W8 = nullptr, const float* ws = nullptr) {
     LinearArgs a = mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, res, ldr, act, out_fp32);
     a.norm_w = norm_w; a.norm_eps = norm_eps;
+    if (W8 && ws) {                       // e4m3 copy of the same weights: only the GEMV streams it
+        a.W8 = W8; a.wscale = ws;
+        if (!vz_gemv_ok(a)) { a.W8 = nullptr; a.wscale = nullptr; }
+    }
     if (norm_w) { ProfScope ps(e, K_GEMV, s); return vz_launch_gemv(a, s); }
     const bool gemv = M <= 8 && (K % 512) == 0 && (size_t)(M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8) * K * 2 + 64 <= 65536;
     ProfScope ps(e, gemv ? K_GEMV : K_GEMM, s);
@@ -304,7 +319,7 @@ extern "C" int vz_engine_destroy(vz_engine* e) {
 }
 
 extern "C" int vz_engine_set_weight(vz_engine* e, const char* name, const void* d_ptr, int dtype, long n_elems) {
-    VZ_CHECK_ARG(e && name && d_ptr && (dtype == 0 || dtype == 1) && n_elems > 0, "set_weight: bad argument");
+    VZ_CHECK_ARG(e && name && d_ptr && dtype >= 0 && dtype <= 2 && n_elems > 0, "set_weight: bad argument");
     VZ_CHECK_ARG(((uintptr_t)d_ptr & 15) == 0, "set_weight: '%s' must be 16-byte aligned", name);
     e->w[name] = Weight{d_ptr, dtype, n_elems};
     e->finalized = false;
@@ -355,10 +370,13 @@ extern "C" int vz_engine_finalize(vz_engine* e) {
     }
     const long qkv_n = (long)(e->Hq_l + 2 * e->Hkv_l) * c.head_dim;
     WB("llm.embed", (long)c.vocab * H); WF("llm.norm", H); WB("llm.lm_head", (long)e->Vp * H);
+    W8("llm.lm_head8", (long)e->Vp * H); WS("llm.lm_heads", e->Vp);
     for (int i = 0; i < c.n_layers && !rc; ++i) {
         const std::string p = "llm." + std::to_string(i) + ".";
         WF(p + "in_norm", H); WF(p + "post_norm", H); WB(p + "qkv.w", qkv_n * H); WB(p + "o.w", H * (long)e->Hq_l * c.head_dim);
         WB(p + "gu.w", 2L * e->I_l * H); WB(p + "down.w", (long)e->I_l * H);
+        W8(p + "qkv.w8", qkv_n * H); WS(p + "qkv.ws", qkv_n); W8(p + "o.w8", H * (long)e->Hq_l * c.head_dim); WS(p + "o.ws", H);
+        W8(p + "gu.w8", 2L * e->I_l * H); WS(p + "gu.ws", 2L * e->I_l); W8(p + "down.w8", (long)e->I_l * H); WS(p + "down.ws", H);
     }
     if (rc) return rc;
     e->finalized = true;
@@ -593,7 +611,10 @@ static int lm_head_logits(vz_engine* e, const bf16_t* h, int rows, float* out, h
     int rc = VZ_OK;
     const bf16_t* lm = WB("llm.lm_head", (long)e->Vp * H);
     if (rc) return rc;
-    if (tp_local(e)) return linear(e, 0, h, H, lm, H, out, c.vocab, rows, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps);
+    const unsigned char* lm8 = W8("llm.lm_head8", (long)e->Vp * H);
+    const float* lms = WS("llm.lm_heads", e->Vp);
+    if (rc) return rc;
+    if (tp_local(e)) return linear(e, 0, h, H, lm, H, out, c.vocab, rows, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps, lm8, lms);
     const size_t local_off = ((size_t)e->tp * rows * e->Vp + 3) & ~(size_t)3;      // the GEMM wants a 16-byte-aligned output base
     const size_t need = local_off + (size_t)rows * e->Vp;
     if (need > e->gather_floats) {
@@ -602,7 +623,7 @@ static int lm_head_logits(vz_engine* e, const bf16_t* h, int rows, float* out, h
         e->gather_floats = need;
     }
     float* local = e->d_gather + local_off;
-    RC(linear(e, 0, h, H, lm, H, local, e->Vp, rows, e->Vp, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps));
+    RC(linear(e, 0, h, H, lm, H, local, e->Vp, rows, e->Vp, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps, lm8, lms));
     if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
     ncclResult_t r = ncclAllGather(local, e->d_gather, (size_t)rows * e->Vp, ncclFloat, e->comm, s);
     if (r != ncclSuccess) { vz_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
@@ -768,7 +789,8 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
     { ProfScope ps(e, K_OTHER, s); RC(vz_launch_embed_tokens(cur, B, H, WB("llm.embed", (long)c.vocab * H), x, s)); }
     for (int i = 0; i < c.n_layers; ++i) {
         const std::string p = "llm." + std::to_string(i) + ".";
-        RC(linear(e, 0, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps));
+        RC(linear(e, 0, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps,
+                  W8(p + "qkv.w8", (long)QKV * H), WS(p + "qkv.ws", QKV)));
         {
             ProfScope ps(e, K_ATTN_DEC, s);
             AttnDecodeFusedArgs a;
@@ -778,10 +800,13 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
             a.scale = 0.08838834764831845f;
             RC(vz_launch_attn_decode_fused(a, s));
         }
-        RC(linear(e, 0, att, A, WB(p + "o.w", (long)H * A), A, x, H, B, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s));
+        RC(linear(e, 0, att, A, WB(p + "o.w", (long)H * A), A, x, H, B, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
+                  W8(p + "o.w8", (long)H * A), WS(p + "o.ws", H)));
         RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
-        RC(linear(e, 0, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps));
-        RC(linear(e, 0, act, I, WB(p + "down.w", (long)I * H), I, x, H, B, H, I, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s));
+        RC(linear(e, 0, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps,
+                  W8(p + "gu.w8", 2L * I * H), WS(p + "gu.ws", 2L * I)));
+        RC(linear(e, 0, act, I, WB(p + "down.w", (long)I * H), I, x, H, B, H, I, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
+                  W8(p + "down.w8", (long)I * H), WS(p + "down.ws", H)));
         RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
         if (rc) return rc;
     }

@@ -11,6 +11,12 @@
 // HBM latency of the first tile hides under it.  Accumulation: v_dot2c_f32_bf16 into fp32, wave
 // reduction, then the same epilogues as the tile GEMM (bias / act / SwiGLU pair / residual /
 // bf16|fp32 out).
+//
+// FP8 weights (W8A16, SURVEY config 5 "fp8 weights"): the same stream at 1 byte per weight.  Rows are OCP e4m3 with one
+// power-of-two scale per output row (vz_hip/quant.py), so the dequantised weight 2^e * fp8 is EXACTLY a bf16 number: a
+// lane's 16 weights per load are widened to packed bf16 pairs (v_cvt_scalef32_pk_bf16_fp8, exact) and go
+// through the same v_dot2c_f32_bf16 as the bf16 stream; the row's 2^e multiplies the fp32 sum once.  The prefill GEMMs
+// run on the bf16 copy of the same dequantised weights, so prefill and decode see one and the same model.
 #include "vz_common.h"
 
 namespace {
@@ -19,6 +25,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct GemvParams {
     const bf16_t* A; const bf16_t* W; void* C;
+    const unsigned char* W8; const float* wscale;     // FP8 instantiation: e4m3 rows [N][ldw] + fp32 2^e per row
     const float* bias; const bf16_t* residual; const float* norm_w;
     int M, N, K, lda, ldw, ldc, ldr;
     int act, out_fp32, units;
@@ -36,8 +43,20 @@ __device__ __forceinline__ float dot8(const u32x4 w, const u32x4 x, float acc) {
     return acc;
 }
 
+// 16 e4m3 weights of one lane -> 16 bf16 (two u32x4 of packed pairs, k order preserved); exact.
+// v_cvt_scalef32_pk_bf16_fp8 widens two fp8 of a dword half to a packed bf16 pair in one instruction (scale 1.0).
+__device__ __forceinline__ unsigned fp8x2_to_bf16x2(unsigned w, bool hi_half) {
+    return hi_half ? __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true))
+                   : __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+}
+__device__ __forceinline__ void fp8x16_to_bf16(const u32x4 w, u32x4& lo, u32x4& hi) {
+    const unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    lo = (u32x4){fp8x2_to_bf16x2(w0, false), fp8x2_to_bf16x2(w0, true), fp8x2_to_bf16x2(w1, false), fp8x2_to_bf16x2(w1, true)};
+    hi = (u32x4){fp8x2_to_bf16x2(w2, false), fp8x2_to_bf16x2(w2, true), fp8x2_to_bf16x2(w3, false), fp8x2_to_bf16x2(w3, true)};
+}
+
 template <bool NT>
-__device__ __forceinline__ u32x4 ldw(const bf16_t* p) {
+__device__ __forceinline__ u32x4 ldw(const void* p) {
     if (NT) return __builtin_nontemporal_load((const u32x4*)p);
     return *(const u32x4*)p;
 }
@@ -48,17 +67,21 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-// MB: activation rows (1,2,4,8); R: weight rows per wave pass (2 or 4); U: 512-element chunks in flight per row;
-// NT: non-temporal weight loads.  A "unit" is R consecutive weight rows, or for SwiGLU R/2 outputs
+// MB: activation rows (1,2,4,8); R: weight rows per wave pass (2 or 4); U: chunks (one 16-byte load per lane: 512 bf16 or
+// 1024 fp8 weights of a row) in flight per row; NT: non-temporal weight loads; FP8: 1-byte e4m3 weights + per-row scale.  A "unit" is R consecutive weight rows, or for SwiGLU R/2 outputs
 // (gate row g, up row g+16 of the [16 gate | 16 up] interleaved layout).
-template <int MB, int R, int U, bool NT>
+template <int MB, int R, int U, bool NT, bool FP8>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
+    constexpr int EPL = FP8 ? 16 : 8;            // weights per lane per load
+    constexpr int CH = 64 * EPL;                 // k per chunk
+    constexpr int WBYTES = FP8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // xs[MB][K] bf16, then scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = p.K;
     float* red = (float*)(smem + (size_t)MB * K * 2);
     const bool swiglu = p.act == VZ_ACT_SWIGLU;
-    const int nchunk = K >> 9;
+    const int nchunk = K / CH;
+    const char* wbase = FP8 ? (const char*)p.W8 : (const char*)p.W;
 
     auto row_of = [&](int u, int r) -> int {
         if (swiglu) {                                  // outputs j = u*(R/2) + r/2 ; r even = gate, odd = up
@@ -75,10 +98,10 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
     if (u_first < p.units) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const bf16_t* wp = p.W + (size_t)row_of(u_first, r) * p.ldw + lane * 8;
+            const char* wp = wbase + ((size_t)row_of(u_first, r) * p.ldw + lane * EPL) * WBYTES;
 #pragma unroll
             for (int c = 0; c < U; ++c)
-                if (c < nchunk) wreg[r][c] = ldw<NT>(wp + c * 512);
+                if (c < nchunk) wreg[r][c] = ldw<NT>(wp + (size_t)c * CH * WBYTES);
         }
     }
 
@@ -126,25 +149,38 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
-        const bf16_t* wp[R];
+        const char* wp[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) wp[r] = p.W + (size_t)row_of(u, r) * p.ldw + lane * 8;
+        for (int r = 0; r < R; ++r) wp[r] = wbase + ((size_t)row_of(u, r) * p.ldw + lane * EPL) * WBYTES;
         for (int c0 = 0; c0 < nchunk; c0 += U) {
             if (!(u == u_first && c0 == 0)) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int c = 0; c < U; ++c)
-                        if (c0 + c < nchunk) wreg[r][c] = ldw<NT>(wp[r] + (c0 + c) * 512);
+                        if (c0 + c < nchunk) wreg[r][c] = ldw<NT>(wp[r] + (size_t)(c0 + c) * CH * WBYTES);
             }
 #pragma unroll
             for (int c = 0; c < U; ++c) {
                 if (c0 + c < nchunk) {
+                    if constexpr (FP8) {
+                        u32x4 wl[R], wh[R];
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        const u32x4 xv = *(const u32x4*)((const bf16_t*)smem + (size_t)m * K + (c0 + c) * 512 + lane * 8);
+                        for (int r = 0; r < R; ++r) fp8x16_to_bf16(wreg[r][c], wl[r], wh[r]);
 #pragma unroll
-                        for (int r = 0; r < R; ++r) acc[r][m] = dot8(wreg[r][c], xv, acc[r][m]);
+                        for (int m = 0; m < MB; ++m) {
+                            const bf16_t* xp = (const bf16_t*)smem + (size_t)m * K + (c0 + c) * CH + lane * 16;
+                            const u32x4 x0 = *(const u32x4*)xp, x1 = *(const u32x4*)(xp + 8);
+#pragma unroll
+                            for (int r = 0; r < R; ++r) acc[r][m] = dot8(wh[r], x1, dot8(wl[r], x0, acc[r][m]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) {
+                            const u32x4 xv = *(const u32x4*)((const bf16_t*)smem + (size_t)m * K + (c0 + c) * 512 + lane * 8);
+#pragma unroll
+                            for (int r = 0; r < R; ++r) acc[r][m] = dot8(wreg[r][c], xv, acc[r][m]);
+                        }
                     }
                 }
             }
@@ -154,6 +190,14 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
 #pragma unroll
             for (int m = 0; m < MB; ++m) acc[r][m] = wave_sum(acc[r][m]);
         if (lane == 0) {
+            if constexpr (FP8) {      // the row's power-of-two scale, once per output
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float sc = p.wscale[row_of(u, r)];
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) acc[r][m] *= sc;
+                }
+            }
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
                 if (m >= p.M) break;
@@ -186,7 +230,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
 
 int g_gemv_variant = 0;   // 0 = production choice; >0 = tuning variants (tools/bench_kernels.py)
 
-template <int MB, int R, int U, bool NT>
+template <int MB, int R, int U, bool NT, bool FP8 = false>
 int launch_variant(const GemvParams& p0, hipStream_t s, size_t lds) {
     GemvParams p = p0;
     p.units = p.act == VZ_ACT_SWIGLU ? p.N / R : (p.N + R - 1) / R;     // SwiGLU: R/2 outputs of N/2 per unit
@@ -194,16 +238,20 @@ int launch_variant(const GemvParams& p0, hipStream_t s, size_t lds) {
     if (blocks > 2048) blocks = 2048;
     static bool attr = false;
     if (!attr) {
-        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<MB, R, U, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<MB, R, U, NT, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr = true;
     }
-    vz_launch_timed(gemv_bf16_kernel<MB, R, U, NT>, dim3(blocks), dim3(256), lds, s, p);
+    vz_launch_timed(gemv_bf16_kernel<MB, R, U, NT, FP8>, dim3(blocks), dim3(256), lds, s, p);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
 
 template <int MB>
 int launch_mb(const GemvParams& p, hipStream_t s, size_t lds) {
+    if (p.W8) {       // 2 rows x up to 8 chunks of 1024 k per wave (measured faster than 4 rows x 4: 13.5 vs 15.3 us on down-proj)
+        if (g_gemv_variant == 1) return launch_variant<MB, 4, 4, true, true>(p, s, lds);
+        return launch_variant<MB, 2, 8, true, true>(p, s, lds);
+    }
     switch (g_gemv_variant) {
         case 1: return launch_variant<MB, 2, 4, false>(p, s, lds);
         case 2: return launch_variant<MB, 2, 8, false>(p, s, lds);
@@ -220,7 +268,8 @@ int launch_mb(const GemvParams& p, hipStream_t s, size_t lds) {
 void vz_set_gemv_variant(int v) { g_gemv_variant = v; }
 
 bool vz_gemv_ok(const LinearArgs& a) {
-    if (a.M > 8 || (a.K % 512) != 0) return false;
+    if (a.M > 8 || (a.K % (a.W8 ? 1024 : 512)) != 0) return false;
+    if (a.W8 && (!a.wscale || (a.ldw & 15) != 0 || ((uintptr_t)a.W8 & 15) != 0)) return false;
     if (a.act == VZ_ACT_SWIGLU && (a.N % 64) != 0) return false;
     const int mb = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
     return (size_t)mb * a.K * 2 + 64 <= 64 * 1024;
@@ -231,10 +280,14 @@ int vz_init_gemv_kernels() {
     // first use never happens inside a stream capture
     static bool done = false;
     if (done) return VZ_OK;
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<1, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<2, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<4, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<8, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<1, 2, 8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<1, 2, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<2, 2, 8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<2, 2, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<4, 2, 8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<4, 2, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<8, 2, 8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<8, 2, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     done = true;
     return VZ_OK;
 }
@@ -242,9 +295,11 @@ int vz_init_gemv_kernels() {
 int vz_launch_gemv(const LinearArgs& a, hipStream_t s) {
     int rc = vz_linear_check_common(a);
     if (rc) return rc;
-    VZ_CHECK_ARG(vz_gemv_ok(a), "gemv: needs M <= 8, K %% 512 == 0 and M*K*2 <= 64 KiB (M=%d K=%d)", a.M, a.K);
+    VZ_CHECK_ARG(vz_gemv_ok(a), "gemv: needs M <= 8, K %% 512 == 0 (fp8 weights: K %% 1024 == 0, 16-byte-aligned rows, scales) and "
+                                "M*K*2 <= 64 KiB (M=%d K=%d)", a.M, a.K);
     GemvParams p;
     p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.residual = a.residual; p.norm_w = a.norm_w;
+    p.W8 = a.W8; p.wscale = a.wscale;
     p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr;
     p.act = a.act; p.out_fp32 = a.out_fp32; p.norm_eps = a.norm_eps; p.units = 0;
     const int mb = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;

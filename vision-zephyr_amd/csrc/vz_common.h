@@ -79,6 +79,8 @@ struct LinearArgs {
     int act; int out_fp32;
     // optional fused RMSNorm prologue (GEMV path only): x <- bf16(norm_w * x * rsqrt(mean(x^2)+eps))
     const float* norm_w; float norm_eps;
+    // optional e4m3 copy of W (rows [N][ldw] bytes) + one fp32 power-of-two scale per row: GEMV path streams these instead
+    const unsigned char* W8 = nullptr; const float* wscale = nullptr;
 };
 int vz_launch_gemm(const LinearArgs& a, hipStream_t s);
 int vz_linear_check_common(const LinearArgs& a);

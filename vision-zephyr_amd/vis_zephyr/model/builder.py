@@ -27,8 +27,11 @@ def _load_config(path: str) -> VisZephyrConfig:
 
 def load_pretrained_model(model_path, model_base, model_name, load_8bit: bool = False, load_4bit: bool = False,
                           device_map="auto", device="cuda", **kwargs):
-    if load_8bit or load_4bit:
-        raise NotImplementedError("bitsandbytes int8 / nf4 weights are not built in the MI355X engine (bf16 weights only)")
+    if load_4bit:
+        raise NotImplementedError("nf4 weights are not built in the MI355X engine (bf16, or 8-bit e4m3 via load_8bit)")
+    # load_8bit: the reference quantises the LLM linears to int8 through bitsandbytes (ref builder.py:33-34); the MI355X
+    # engine's 8-bit form is W8A16 - OCP e4m3 weights with one power-of-two scale per row, streamed by the decode GEMV
+    # (vz_hip/quant.py); activations and the prefill GEMMs stay bf16
     if "zephyr" not in model_name.lower():
         raise ValueError(f"Unsupported model name: {model_name}. Only Zephyr models are supported at the moment.")
     from transformers import AutoTokenizer
@@ -52,7 +55,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit: bool = 
         raise FileNotFoundError(f"mm_vision_tower = {clip_dir!r} must be a local directory holding the CLIP ViT-L/14-336 "
                                 "weights and preprocessor_config.json (no network access)")
     dev = "cuda:0" if device == "cuda" else device
-    model = VisZephyrForCausalLM(config, device=dev, max_ctx=kwargs.pop("max_ctx", 4096))
+    model = VisZephyrForCausalLM(config, device=dev, max_ctx=kwargs.pop("max_ctx", 4096), weight_fp8=bool(load_8bit))
     model.load_state_dict_stream(W.resize_vocab(W.iter_reference_checkpoint(model_path, model_base, clip_dir, lora=lora),
                                                 len(tokenizer)))
     tower = model.get_vision_tower()

@@ -104,12 +104,13 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
 
     def __init__(self, config, device: Union[str, torch.device] = "cuda:0", max_batch: int = 1,
                  max_ctx: int = 4096, max_tiles: int = 8, max_text: int = 2048, engine: Optional[Engine] = None,
-                 tp_size: int = 1, tp_rank: int = 0):
+                 tp_size: int = 1, tp_rank: int = 0, weight_fp8: bool = False):
         self.config = config
         self.arch = arch_from_config(config)
         self.engine = engine if engine is not None else Engine(self.arch, device=device, max_batch=max_batch,
                                                                max_ctx=max_ctx, max_tiles=max_tiles,
-                                                               max_text=max_text, tp_size=tp_size, tp_rank=tp_rank)
+                                                               max_text=max_text, tp_size=tp_size, tp_rank=tp_rank,
+                                                               weight_fp8=weight_fp8)
         self.device = self.engine.device
         self.dtype = torch.bfloat16
         self.model = VisZephyrModel(config, self)

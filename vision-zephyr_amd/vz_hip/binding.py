@@ -31,7 +31,7 @@ class VzConfig(C.Structure):
         ("qf_eps", C.c_float),
         ("fusion_groups", C.c_int), ("fusion_layers_per_group", C.c_int),
         ("max_batch", C.c_int), ("max_ctx", C.c_int), ("max_tiles", C.c_int), ("max_text", C.c_int),
-        ("tp_size", C.c_int), ("tp_rank", C.c_int), ("clip_keep_cls", C.c_int),
+        ("tp_size", C.c_int), ("tp_rank", C.c_int), ("clip_keep_cls", C.c_int), ("weight_fp8", C.c_int),
     ]
 
 
@@ -65,6 +65,7 @@ SYMBOLS = {
     "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
     "vz_tune_set": (_I, [_I, _I]),
     "vz_engine_resize_vocab": (_I, [_P, _I]),
+    "vz_op_linear_fp8": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _F, _P]),
     "vz_tp_all_gather": (_I, [_P, _P, _P, C.c_size_t, _P]),
     "vz_prof_enable": (_I, [_P, _I, _I]),
     "vz_prof_read": (_I, [_P, C.POINTER(C.c_long), C.POINTER(C.c_double)]),
@@ -150,6 +151,22 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: int 
         check(lib().vz_op_linear(*args))
     else:
         check(lib().vz_op_linear_impl(impl, *args))
+    return out
+
+
+def linear_fp8(x: torch.Tensor, w8: torch.Tensor, scale: torch.Tensor, bias=None, residual=None, act: int = ACT_NONE,
+               out_fp32=False, norm_w=None, norm_eps: float = 0.0) -> torch.Tensor:
+    """W8A16 weight stream: epi(x[M<=8,K] @ (scale[:,None] * e4m3(w8))[N,K]^T); x bf16, w8 uint8 (e4m3 bytes), scale fp32 [N]."""
+    _need_cuda(x, w8, scale, bias, residual, norm_w)
+    assert x.dtype == torch.bfloat16 and w8.dtype == torch.uint8 and scale.dtype == torch.float32
+    assert x.dim() == 2 and w8.dim() == 2 and x.stride(1) == 1 and w8.stride(1) == 1
+    M, K = x.shape
+    N = w8.shape[0]
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    out = torch.empty(M, n_out, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=x.device)
+    check(lib().vz_op_linear_fp8(ptr(x), x.stride(0), ptr(w8), w8.stride(0), ptr(scale), ptr(out), out.stride(0), M, N, K,
+                                 ptr(bias), ptr(residual), 0 if residual is None else residual.stride(0), act, int(out_fp32),
+                                 ptr(norm_w), float(norm_eps), stream_ptr(x.device)))
     return out
 
 

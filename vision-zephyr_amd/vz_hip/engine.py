@@ -38,7 +38,7 @@ def rope_tables(cfg: ArchConfig, max_pos: int) -> Tuple[torch.Tensor, torch.Tens
 
 class Engine:
     def __init__(self, cfg: ArchConfig, device="cuda:0", max_batch: int = 1, max_ctx: int = 4096,
-                 max_tiles: int = 8, max_text: int = 2048, tp_size: int = 1, tp_rank: int = 0):
+                 max_tiles: int = 8, max_text: int = 2048, tp_size: int = 1, tp_rank: int = 0, weight_fp8: bool = False):
         self.lib = B.load_library()            # raises when the HIP library is absent: no fallback
         if not torch.cuda.is_available():
             raise RuntimeError("vz_hip.Engine needs a ROCm GPU (gfx950); there is no CPU fallback")
@@ -58,7 +58,8 @@ class Engine:
             qf_heads=cfg.qf_heads, qf_kv_dim=cfg.qf_kv_dim, qf_eps=cfg.qf_eps, fusion_groups=cfg.fusion_groups,
             fusion_layers_per_group=cfg.fusion_layers_per_group, max_batch=max_batch, max_ctx=max_ctx,
             max_tiles=max_tiles, max_text=max_text, tp_size=tp_size, tp_rank=tp_rank,
-            clip_keep_cls=int(cfg.clip_keep_cls))
+            clip_keep_cls=int(cfg.clip_keep_cls), weight_fp8=int(weight_fp8))
+        self.weight_fp8 = bool(weight_fp8)
         h = C.c_void_p()
         B.check(self.lib.vz_engine_create(C.byref(c), C.byref(h)))
         self.h = h
@@ -301,11 +302,30 @@ class Engine:
         """hash-generated weights, produced on the device (bit-identical to the CPU generator)."""
         self.load_weights(iter_state_dict(self.cfg, seed, device=self.device))
 
+    _FP8_NAMES = re.compile(r"llm\.(\d+\.(qkv|o|gu|down)\.w|lm_head)$")
+
+    def _quantize_decode_weights(self):
+        """weight_fp8: every decode-side Zephyr linear gets an e4m3 copy + per-row 2^e scales (vz_hip/quant.py); the bf16
+        tensor is replaced by the exactly-equal dequantised values, so prefill (bf16 MFMA) and decode (fp8 stream) agree."""
+        from . import quant
+        for name in [n for n in self.w if self._FP8_NAMES.match(n)]:
+            n8, ns = (name + "8", name + "s") if name.endswith("lm_head") else (name + "8", name[:-1] + "ws")
+            if n8 in self.w:
+                continue
+            w = self.w[name]
+            w8, scale = quant.quantize_rows(w)
+            w.copy_(quant.dequantize_rows(w8, scale).to(torch.bfloat16))
+            self.w[n8], self.w[ns] = w8.contiguous(), scale.contiguous()
+            self._registered.discard(name)
+
     def finalize(self):
+        if self.weight_fp8:
+            self._quantize_decode_weights()
         for name, t in self.w.items():
             if name in self._registered:
                 continue
-            B.check(self.lib.vz_engine_set_weight(self.h, name.encode(), B.ptr(t), 0 if t.dtype == torch.bfloat16 else 1,
+            B.check(self.lib.vz_engine_set_weight(self.h, name.encode(), B.ptr(t),
+                                                  0 if t.dtype == torch.bfloat16 else (2 if t.dtype == torch.uint8 else 1),
                                                   t.numel()))
             self._registered.add(name)
         B.check(self.lib.vz_engine_finalize(self.h))
