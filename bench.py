@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 
 
-def build_model(n_layers, device, max_ctx, tp_size=1, tp_rank=0):
+def build_model(n_layers, device, max_ctx, tp_size=1, tp_rank=0, weight_fp8=False):
     from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
     hf = VisZephyrConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=n_layers, num_attention_heads=32,
                          num_key_value_heads=8, vocab_size=32000, rms_norm_eps=1e-5, sliding_window=4096,
@@ -47,7 +47,7 @@ def build_model(n_layers, device, max_ctx, tp_size=1, tp_rank=0):
     hf.mm_hidden_size = 5120
     hf.mm_vision_select_layer = "-2,-5,-8,-11,6"
     return VisZephyrForCausalLM.from_synthetic(hf, seed=0, device=device, max_batch=1, max_ctx=max_ctx, max_tiles=5,
-                                               max_text=2048, tp_size=tp_size, tp_rank=tp_rank)
+                                               max_text=2048, tp_size=tp_size, tp_rank=tp_rank, weight_fp8=weight_fp8)
 
 
 def algorithmic_work(cfg, S, n_tiles):
@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--layers", type=int, default=32, help="decoder layers (32 = Zephyr-7B; anything else is a debug run)")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra W8A16 (e4m3 weight stream) measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -215,6 +216,50 @@ def main():
                         "traffic": None, "launches": n_l, "total_ms": round(ms, 3),
                         "algorithmic_flops": pre_flops}
 
+    # ---- extra leg (never `value`): the same request on the W8A16 engine of SURVEY config 5 - e4m3 weights with per-row
+    # power-of-two scales streamed by the decode GEMV, bf16 activations, bf16 MFMA prefill on the dequantised weights ----
+    fp8_leg = None
+    if world == 1 and not args.no_fp8_leg:
+        try:
+            del model, eng
+            torch.cuda.empty_cache()
+            model8 = build_model(args.layers, device, max_ctx=S + n_new + 16, weight_fp8=True)
+
+            def step8():
+                tm = {}
+                t0 = time.perf_counter()
+                out = model8.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n_new, eos_token_id=None,
+                                      pad_token_id=2, use_cache=True, timing=tm)
+                torch.cuda.synchronize()
+                assert out.shape == (1, n_new)
+                return tm["t_first_token"] - t0, time.perf_counter() - tm["t_first_token"]
+            step8()
+            r8 = [step8() for _ in range(args.steps)]
+            e8 = model8.engine
+            emb8 = model8.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles])[4]
+            _, last8 = e8.prefill(emb8, [S])
+            e8.decode_begin(last8.argmax(-1).to(torch.int32), [S], [S])
+            e8.prof_enable(True, B.K_GEMV)
+            e8.decode_steps(16)
+            torch.cuda.synchronize()
+            n_l8, ms8 = e8.prof_read()
+            e8.prof_enable(False)
+            w_bytes8 = algorithmic_work(cfg, S, n_tiles)[0] // 2 + 4 * (cfg.n_layers * ((cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim
+                                                                                         + 2 * cfg.hidden + 2 * cfg.inter) + cfg.vocab)
+            ach8 = w_bytes8 / (4 * cfg.n_layers + 1) / (ms8 / max(1, n_l8) * 1e-3) / 1e9
+            fp8_leg = {"value": round((n_new - 1) * args.steps / sum(b for _, b in r8), 2), "unit": "tokens/s",
+                       "image_to_first_token_ms": round(sum(a for a, _ in r8) / args.steps * 1e3, 2),
+                       "dtype": "w8a16: OCP e4m3 weights + per-row 2^e scales (decode stream), bf16 activations, bf16 MFMA prefill on the "
+                                "dequantised weights",
+                       "roofline": {"bound": "hbm", "kernel": "gemv_bf16_kernel<.., FP8> (decode weight stream, 1 B per weight)",
+                                    "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach8 / HBM_PEAK_GBS, 4),
+                                    "traffic": None, "launches": n_l8, "avg_launch_ms": round(ms8 / max(1, n_l8), 5),
+                                    "algorithmic_bytes_per_launch": int(w_bytes8 / (4 * cfg.n_layers + 1))}}
+            del model8, e8
+            torch.cuda.empty_cache()
+        except Exception as ex:       # the bf16 numbers stand on their own
+            fp8_leg = {"value": None, "error": f"{type(ex).__name__}: {ex}"}
+
     # ---- N > 1: a guarded tensor-parallel leg beside the replica measurement.  Every rank starts a CHILD process that
     # runs this script in tp mode (its own rendezvous port), so a failure or hang inside the collectives cannot take the
     # replica numbers down with it; rank 0 attaches the child's result (or the reason it is missing). ----
@@ -272,6 +317,8 @@ def main():
     }
     if tp_leg is not None:
         line["tensor_parallel"] = tp_leg
+    if fp8_leg is not None:
+        line["fp8_weights"] = fp8_leg
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

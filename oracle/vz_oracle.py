@@ -246,11 +246,12 @@ def fake_quantize_rows(w: torch.Tensor) -> torch.Tensor:
 
 def quantize_state_dict(sd):
     """the model the weight_fp8 engine computes with: every Zephyr linear + lm_head row-quantised (rows are independent, so
-    quantising q/k/v or gate/up before the engine stacks them gives the same bytes); embeddings, norms, CLIP, Q-Former untouched."""
+    quantising q/k/v or gate/up before the engine stacks them gives the same bytes); embeddings, norms, CLIP, Q-Former untouched.
+    The quantiser starts from the bf16 weights (what a checkpoint holds and what the engine stores), not from fp32 masters."""
     out = dict(sd)
     for k, v in sd.items():
         if k == "lm_head.weight" or (k.startswith("model.layers.") and k.endswith(_FP8_KEYS)):
-            out[k] = fake_quantize_rows(v)
+            out[k] = fake_quantize_rows(v.bfloat16().float())
     return out
 
 

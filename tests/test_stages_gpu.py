@@ -407,3 +407,62 @@ def test_resize_token_embeddings_live(env):
     finally:
         model.resize_token_embeddings(cfg.vocab)
     assert torch.equal(model(input_ids=ids).logits, before)
+
+
+def test_fp8_weight_engine_matches_quantized_oracle(env):
+    """W8A16 (SURVEY config 5; `load_8bit` of the drop-in builder): the engine's decode GEMVs stream e4m3 weights with one
+    power-of-two scale per row, its prefill GEMMs run on the bf16 copy of the same dequantised weights.  Checked against
+    the oracle running the identically quantised state dict: packed weights bit-exact, prefill logits in the bf16 band,
+    decode (fp8 stream) = prefill (bf16 MFMA) under teacher forcing, greedy ids up to oracle near-ties."""
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    from vz_hip import quant
+    O, sd, synth, cfg = env["O"], env["sd"], env["synth"], env["cfg"]
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.n_layers,
+                         num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab,
+                         rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, sliding_window=cfg.sliding_window,
+                         eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    hf.mm_hidden_size = 5120
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=256, max_tiles=1, max_text=64, weight_fp8=True)
+    eng = model.engine
+    sdq = O.quantize_state_dict(sd)
+    # the engine's bf16 tensors hold exactly the dequantised e4m3 weights, and those are the oracle's
+    qkv = torch.cat([sdq[f"model.layers.1.self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+    assert torch.equal(eng.w["llm.1.qkv.w"].float().cpu(), qkv)
+    assert torch.equal(quant.dequantize_rows(eng.w["llm.1.qkv.w8"], eng.w["llm.1.qkv.ws"]).cpu(), qkv)
+    assert torch.equal(eng.w["llm.lm_head"].float().cpu(), sdq["lm_head.weight"])
+    g = eng.w["llm.0.gu.w"].float().cpu().view(-1, 2, 16, cfg.hidden)
+    assert torch.equal(g[:, 0].reshape(-1, cfg.hidden), sdq["model.layers.0.mlp.gate_proj.weight"])
+    assert torch.equal(eng.w["llm.embed"].float().cpu(), sd["model.embed_tokens.weight"].bfloat16().float())   # not quantised
+    # prefill logits (bf16 MFMA on dequantised weights) in the bf16 band of the quantised-weight oracle
+    ids = synth.synth_ids(40, cfg.vocab, image_pos=-1, seed=9)
+    x_or = O.embed_tokens(sd, ids.unsqueeze(0), O.BF16)
+    lo_bf, _ = O.llm_forward(cfg, sdq, x_or, P=O.BF16)
+    lo_32, _ = O.llm_forward(cfg, sdq, O.embed_tokens(sd, ids.unsqueeze(0), O.FP32), P=O.FP32)
+    emb = eng.embed_tokens(ids).unsqueeze(0)
+    full, _ = eng.prefill(emb, [40], all_logits=True, last_logits=False)
+    band("fp8 prefill logits", full, lo_bf, lo_32)
+    # quantisation is visible: the unquantised oracle is measurably further away than the band
+    lo_unq, _ = O.llm_forward(cfg, sd, O.embed_tokens(sd, ids.unsqueeze(0), O.FP32), P=O.FP32)
+    assert errs(full, lo_unq)[1] > 2 * errs(full, lo_32)[1]
+    # teacher forcing: decode steps (fp8 weight stream) reproduce the prefill logits (bf16 MFMA GEMMs)
+    S0 = 33
+    _, last = eng.prefill(emb[:, :S0].contiguous(), [S0], all_logits=False, last_logits=True)
+    check_close("fp8 last-row logits (GEMV) vs all-rows (GEMM)", last[0], full[0, S0 - 1], 3e-2, 6e-3)
+    eng.decode_begin(ids[S0:S0 + 1].to(torch.int32), [S0], [S0])
+    _, lg = eng.decode_steps(1, return_logits=True)
+    check_close("fp8 decode step vs prefill", lg[0, 0], full[0, S0], 3e-2, 6e-3)
+    # greedy generation against the quantised-weight oracle
+    n_new = 6
+    got = model.generate(input_ids=ids.unsqueeze(0), do_sample=False, max_new_tokens=n_new, eos_token_id=None, pad_token_id=2)
+    ref_ids, ref_logits = O.greedy_generate(cfg, sdq, x_or, n_new, P=O.BF16, return_logits=True)
+    top2 = ref_logits[0].topk(2, dim=-1).values
+    margin = (top2[:, 0] - top2[:, 1]) / ref_logits[0].abs().amax(-1)
+    for t in range(n_new):
+        if int(got[0, t]) != int(ref_ids[0, t]):
+            assert float(margin[t]) < 2e-3, f"step {t}: id {int(got[0, t])} vs oracle {int(ref_ids[0, t])}, margin {float(margin[t]):.2e}"
+            break
+    record("generate fp8", got=got[0].tolist(), oracle_bf16_quantized=ref_ids[0].tolist(), min_margin=float(margin.min()))
+    del model
+    torch.cuda.empty_cache()
