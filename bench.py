@@ -274,7 +274,7 @@ def main():
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(min(args.steps, 2)), "--warmup", "1",
                "--layers", str(args.layers), "--new-tokens", str(args.new_tokens), "--no-cpu-baseline"]
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
             if rank == 0:
                 lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 if r.returncode == 0 and lines:
@@ -285,7 +285,7 @@ def main():
                     tp_leg = {"value": None, "error": f"child rc={r.returncode}: {(r.stderr or '')[-400:]}"}
         except subprocess.TimeoutExpired:
             if rank == 0:
-                tp_leg = {"value": None, "error": "tensor-parallel child timed out after 420 s"}
+                tp_leg = {"value": None, "error": "tensor-parallel child timed out after 240 s"}
         barrier()
     if rank != 0:
         if dist is not None:

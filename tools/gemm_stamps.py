@@ -2,7 +2,8 @@
 """In-kernel phase timeline of the 256x256 GEMM (stream-K on) for one shape: where a workgroup's time goes.
 
     python tools/gemm_stamps.py M N K [streamk]
-Stamps are s_memrealtime (100 MHz); printed in microseconds relative to the first workgroup's start."""
+Stamps are s_memrealtime (100 MHz); printed in microseconds relative to the first workgroup's start.  Launches are repeated
+for ~1 s first so that the clock the chip settles at under this load is the one measured."""
 import ctypes as C
 import os
 import sys
@@ -19,8 +20,12 @@ sk = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 x = torch.randn(M, K, device="cuda").bfloat16()
 w = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
 B.check(B.lib().vz_tune_set(4, sk))
-for _ in range(5):
-    B.linear(x, w, impl=2)
+import time
+t_end = time.time() + 1.0
+while time.time() < t_end:                 # let DVFS settle under this kernel's load
+    for _ in range(50):
+        B.linear(x, w, impl=2)
+    torch.cuda.synchronize()
 B.check(B.lib().vz_tune_set(6, 1))
 for _ in range(3):
     B.linear(x, w, impl=2)
@@ -34,6 +39,11 @@ t0 = st[:, 0].min()
 us = lambda a: (a - t0) / 100.0
 print(f"shape {M}x{N}x{K} streamk={sk}: {n.value} workgroups; start spread {us(st[:, 0]).max():.1f} us; "
       f"kernel span {us(st[:, 1:15][st[:, 1:15] > 0].max()):.1f} us")
+# shader clock inside the main loop of the first K-slice: delta s_memtime / delta s_memrealtime x 100 MHz (guide, DVFS item 6)
+ok = (st[:, 15] > st[:, 14]) & (st[:, 2] > st[:, 1])
+if ok.any():
+    ghz = (st[ok, 15] - st[ok, 14]) / (st[ok, 2] - st[ok, 1]) * 0.1
+    print(f"  in-kernel shader clock during the main loop: median {np.median(ghz):.2f} GHz (min {ghz.min():.2f}, max {ghz.max():.2f})")
 for seg in range(3):
     b = 1 + seg * 5
     have = st[:, b] > 0

@@ -357,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
         if (late) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
         __builtin_amdgcn_sched_barrier(0);
         if (seg_no < 3) { VZ_STAMP(1 + seg_no * 5) }
+        if (seg_no == 0 && p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = (long long)__builtin_amdgcn_s_memtime();   // core clock
 
         bf16x8 af[4][2], b0f[2][2], b1f[2][2];   // [mt][ks], [nt][ks]
         for (int t = 0; t < nks; ++t) {
@@ -415,6 +416,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
         if (!late) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must not outlive this use of the ring
         if (seg_no < 3) { VZ_STAMP(2 + seg_no * 5) }
+        if (seg_no == 0 && p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = (long long)__builtin_amdgcn_s_memtime();
 
         // ---- a K-slice of a tile: the last slice to arrive finishes the tile, the others park their partial sums ----
         bool finish = true;
