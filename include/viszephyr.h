@@ -216,6 +216,18 @@ int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, const int* 
                         vz_stream stream);
 int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d_logits_dbg, vz_stream stream);
 
+/* ---- anyres preprocessing on the device (ref:vis_zephyr/model/multi_scale_process.py:70-171) ----
+ * vz_op_resample_u8: Pillow's 8-bit LANCZOS `Image.resize` (horizontal pass, 8-bit intermediate, vertical pass) of an
+ * [h, w, 3] u8 image to [h2, w2, 3], bit-exact.  bounds int32 [out, 2] = (first tap, tap count), coefs int32 [out, k] at 22
+ * fractional bits, computed by the host as Pillow's precompute_coeffs / normalize_coeffs_8bpc do (vz_hip/preprocess.py).
+ * d_tmp [h, w2, 3] is needed when both sizes change; equal sizes copy.
+ * vz_op_anyres_tiles: the letterbox paste on black + row-major side x side crops + the global view in front + CLIP rescale /
+ * normalise through a bf16 LUT [3, 256] -> bf16 [1 + grid_w * grid_h, 3, side, side], what the vision tower takes. */
+int vz_op_resample_u8(const void* d_src, int h, int w, void* d_tmp, void* d_dst, int h2, int w2, const int* d_xbounds,
+                      const int* d_xcoefs, int kx, const int* d_ybounds, const int* d_ycoefs, int ky, vz_stream stream);
+int vz_op_anyres_tiles(const void* d_global, const void* d_resized, int nh, int nw, int paste_x, int paste_y, int grid_w,
+                       int grid_h, int side, const void* d_lut, void* d_out, vz_stream stream);
+
 /* argmax over fp32 logits rows: ids int32 [rows] (first maximal index) */
 int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_stream stream);
 

@@ -92,6 +92,43 @@ def bench_gemv_fp8():
         del ws
 
 
+def bench_preprocess():
+    """anyres preprocessing of one 1920 x 804 frame (the VCR movie-still shape of SURVEY config 5): device vs the PIL + numpy host path."""
+    import numpy as np
+    from PIL import Image
+    from vz_hip.preprocess import AnyresPreprocessor
+    pins = [[336, 672], [672, 336], [336, 1008], [1008, 336], [672, 672]]
+    rng = np.random.default_rng(0)
+    for h, w in [(804, 1920), (480, 640)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        pre = AnyresPreprocessor("cuda:0")
+        d_img = torch.from_numpy(img).cuda()
+        pre(d_img, pins)
+        us = min(timed(lambda i: pre(d_img, pins), 20) for _ in range(3))
+        host_img = torch.from_numpy(img)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pre(host_img, pins)
+        torch.cuda.synchronize()
+        us_h2d = (time.perf_counter() - t0) / 5 * 1e6
+        try:
+            from vis_zephyr.model.multi_scale_process import process_any_resolution_image
+            from vis_zephyr.model.vision_encoder.vision_encoder import _make_image_processor
+            proc = _make_image_processor("openai/clip-vit-large-patch14-336", 336)
+            pil = Image.fromarray(img)
+            process_any_resolution_image(pil, proc, pins)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                process_any_resolution_image(pil, proc, pins)
+            cpu_us = (time.perf_counter() - t0) / 3 * 1e6
+        except Exception as ex:      # noqa: BLE001
+            cpu_us = float("nan")
+            print("host path unavailable:", ex)
+        n = len(pre(d_img, pins))
+        print(f"preprocess {h}x{w} -> {n} tiles: device {us:7.1f} us (image resident), {us_h2d:8.1f} us from a host tensor (PCIe + sync); "
+              f"host PIL + CLIPImageProcessor {cpu_us:9.1f} us  ({cpu_us / us:6.1f}x)", flush=True)
+
+
 def bench_gemv_resident():
     """Does a GEMV run faster when its weights sit in the 256 MiB Infinity Cache (read by the previous kernel) than from
     HBM?  Same weights every launch (resident) vs a pool larger than the cache (streamed), per shape."""
@@ -207,6 +244,8 @@ if __name__ == "__main__":
         bench_gemv()
     if what in ("gemm", "all"):
         bench_gemm()
+    if what == "preprocess":
+        bench_preprocess()
     if what == "gemv8":
         bench_gemv_fp8()
     if what == "gemvres":

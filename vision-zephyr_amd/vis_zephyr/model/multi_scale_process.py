@@ -67,6 +67,23 @@ def process_any_resolution_image(image: Image.Image, processor, grid_pinpoints) 
     return torch.cat([processor.preprocess(t, return_tensors="pt")["pixel_values"] for t in tiles], dim=0)
 
 
+_DEVICE_PRE = {}
+
+
+def process_any_resolution_image_device(image, processor, grid_pinpoints, device="cuda:0") -> torch.Tensor:
+    """Same contract as `process_any_resolution_image`, pixel work on the GPU (csrc/preprocess.hip): uint8 RGB image
+    (PIL / numpy / uint8 tensor [H, W, 3]) -> bf16 [1 + n_crops, 3, 336, 336] on `device`, bit-identical to the bf16 cast
+    of the host function's result (Pillow's 8-bit LANCZOS arithmetic is integer and reproduced exactly)."""
+    from vz_hip.preprocess import AnyresPreprocessor
+    side = processor.crop_size["height"] if processor is not None else 336
+    mean = tuple(getattr(processor, "image_mean", None) or (0.48145466, 0.4578275, 0.40821073))
+    std = tuple(getattr(processor, "image_std", None) or (0.26862954, 0.26130258, 0.27577711))
+    key = (str(device), side, mean, std)
+    if key not in _DEVICE_PRE:
+        _DEVICE_PRE[key] = AnyresPreprocessor(device, side, mean, std)
+    return _DEVICE_PRE[key](image, grid_pinpoints)
+
+
 def unpad_image(image_tensor: torch.Tensor, original_size: Tuple[int, int]) -> torch.Tensor:
     """inverse of the letterboxing on a [C, H, W]-like feature map (only reachable from the `unpad` merge types)."""
     ow, oh = original_size

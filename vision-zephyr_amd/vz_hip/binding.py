@@ -65,6 +65,8 @@ SYMBOLS = {
     "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
     "vz_tune_set": (_I, [_I, _I]),
     "vz_engine_resize_vocab": (_I, [_P, _I]),
+    "vz_op_resample_u8": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P]),
+    "vz_op_anyres_tiles": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "vz_op_linear_fp8": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _F, _P]),
     "vz_tp_all_gather": (_I, [_P, _P, _P, C.c_size_t, _P]),
     "vz_prof_enable": (_I, [_P, _I, _I]),
