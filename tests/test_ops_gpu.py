@@ -112,8 +112,9 @@ def test_gemm_swiglu(B, M):
         check_close(f"swiglu impl{impl} M{M}", out, _ref_linear(x, w, None, None, 3), BF16_MAX, BF16_L2)
 
 
+# (4, 4096, 14336) / (2, 1024, 28672): x does not fit 64 KiB of LDS -> the 16-wave workgroup form; (8, 512, 4096): 2 rows per wave
 @pytest.mark.parametrize("M,N,K", [(1, 6144, 4096), (1, 4096, 14336), (2, 4096, 4096), (4, 1024, 4096), (1, 32001, 4096),
-                                   (3, 257, 1024)])
+                                   (3, 257, 1024), (4, 4096, 14336), (2, 1024, 28672), (8, 512, 4096), (5, 6144, 4096)])
 def test_gemv(B, M, N, K):
     x = _rand((M, K), 1.0, 14).bfloat16()
     w = _rand((N, K), 0.03, 15).bfloat16()
@@ -467,10 +468,11 @@ def test_gemv_fp8_weights(B, M, N, K, act):
     assert float((out.float() - same.float()).abs().max()) <= 2 ** -7 * float(same.float().abs().max()) + 1e-6
 
 
-def test_gemv_fp8_fused_rmsnorm(B):
+@pytest.mark.parametrize("M", [2, 4, 7])          # 4, 7: one wave per activation row in the staging prologue
+def test_gemv_fp8_fused_rmsnorm(B, M):
     from vz_hip import quant
     K, N = 4096, 6144
-    x = _rand((2, K), 3.0, 94).bfloat16()
+    x = _rand((M, K), 3.0, 94).bfloat16()
     nw = _rand((K,), 0.2, 95) + 1.0
     w8, scale = quant.quantize_rows(_rand((N, K), 0.02, 96))
     wq = quant.dequantize_rows(w8, scale)

@@ -220,7 +220,7 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
         if (!vz_gemv_ok(a)) { a.W8 = nullptr; a.wscale = nullptr; }
     }
     if (norm_w) { ProfScope ps(e, K_GEMV, s); return vz_launch_gemv(a, s); }
-    const bool gemv = M <= 8 && (K % 512) == 0 && (size_t)(M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8) * K * 2 + 64 <= 65536;
+    const bool gemv = vz_gemv_ok(a);
     ProfScope ps(e, gemv ? K_GEMV : K_GEMM, s);
     (void)klass_hint;
     return vz_launch_linear(a, s);

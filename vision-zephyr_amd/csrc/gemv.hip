@@ -70,15 +70,19 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // MB: activation rows (1,2,4,8); R: weight rows per wave pass (2 or 4); U: chunks (one 16-byte load per lane: 512 bf16 or
 // 1024 fp8 weights of a row) in flight per row; NT: non-temporal weight loads; FP8: 1-byte e4m3 weights + per-row scale.  A "unit" is R consecutive weight rows, or for SwiGLU R/2 outputs
 // (gate row g, up row g+16 of the [16 gate | 16 up] interleaved layout).
-template <int MB, int R, int U, bool NT, bool FP8>
-__global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
+// NW: waves per workgroup.  4 (256 threads, several workgroups per CU) while the staged activations fit 64 KiB; 16 (one
+// 1024-thread workgroup per CU sharing one copy of x, up to 160 KiB) for batched decode through the wide down-projection
+// (4 rows x 14336 = 112 KiB).
+template <int MB, int R, int U, bool NT, bool FP8, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemv_bf16_kernel(GemvParams p) {
+    constexpr int NTHR = NW * 64;
     constexpr int EPL = FP8 ? 16 : 8;            // weights per lane per load
     constexpr int CH = 64 * EPL;                 // k per chunk
     constexpr int WBYTES = FP8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // xs[MB][K] bf16, then scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = p.K;
-    float* red = (float*)(smem + (size_t)MB * K * 2);
+    float* red = (float*)(smem + (size_t)MB * K * 2);     // NW floats
     const bool swiglu = p.act == VZ_ACT_SWIGLU;
     const int nchunk = K / CH;
     const char* wbase = FP8 ? (const char*)p.W8 : (const char*)p.W;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
     };
 
     // ---- first tile of this wave's first unit goes in flight before the prologue ----
-    const int u_first = blockIdx.x * 4 + wave;
+    const int u_first = blockIdx.x * NW + wave;
     u32x4 wreg[R][U];
     if (u_first < p.units) {
 #pragma unroll
@@ -106,16 +110,50 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
     }
 
     // ---- prologue: x (optionally RMS-normalised) -> LDS as bf16 ----
+    if constexpr (MB >= 4) {
+        // one wave per activation row (rows m = wave, wave + NW, ...): the sum of squares is a wave reduction, no workgroup barrier
+        // per row - with 4 or 8 rows the row-after-row form below costs 4-8x the prologue of a single row
+        for (int m = wave; m < MB; m += NW) {
+            bf16_t* xs = (bf16_t*)smem + (size_t)m * K;
+            if (m >= p.M) {
+                for (int k = lane * 8; k < K; k += 64 * 8) *(uint4*)(xs + k) = make_uint4(0, 0, 0, 0);
+                continue;
+            }
+            const bf16_t* x = p.A + (size_t)m * p.lda;
+            if (p.norm_w) {
+                float ss = 0.f;
+                for (int k = lane * 8; k < K; k += 64 * 8) {
+                    const u16x8 v = *(const u16x8*)(x + k);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(v[j]); ss += f * f; }
+                }
+                const float rstd = rsqrtf(wave_sum(ss) / (float)K + p.norm_eps);
+                for (int k = lane * 8; k < K; k += 64 * 8) {
+                    const u16x8 v = *(const u16x8*)(x + k);
+                    const f32x4 w0 = *(const f32x4*)(p.norm_w + k), w1 = *(const f32x4*)(p.norm_w + k + 4);
+                    u16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float wj = j < 4 ? w0[j] : w1[j - 4];
+                        o[j] = f32_to_bf16(wj * (bf16_to_f32(v[j]) * rstd));
+                    }
+                    *(u16x8*)(xs + k) = o;
+                }
+            } else {
+                for (int k = lane * 8; k < K; k += 64 * 8) *(uint4*)(xs + k) = *(const uint4*)(x + k);
+            }
+        }
+    } else {
     for (int m = 0; m < MB; ++m) {
         bf16_t* xs = (bf16_t*)smem + (size_t)m * K;
         if (m >= p.M) {
-            for (int k = tid * 8; k < K; k += 256 * 8) *(uint4*)(xs + k) = make_uint4(0, 0, 0, 0);
+            for (int k = tid * 8; k < K; k += NTHR * 8) *(uint4*)(xs + k) = make_uint4(0, 0, 0, 0);
             continue;
         }
         const bf16_t* x = p.A + (size_t)m * p.lda;
         if (p.norm_w) {
             float ss = 0.f;
-            for (int k = tid * 8; k < K; k += 256 * 8) {
+            for (int k = tid * 8; k < K; k += NTHR * 8) {
                 const u16x8 v = *(const u16x8*)(x + k);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(v[j]); ss += f * f; }
@@ -124,9 +162,11 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
             __syncthreads();
             if (lane == 0) red[wave] = ss;
             __syncthreads();
-            const float tot = red[0] + red[1] + red[2] + red[3];
+            float tot = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) tot += red[w2];
             const float rstd = rsqrtf(tot / (float)K + p.norm_eps);
-            for (int k = tid * 8; k < K; k += 256 * 8) {
+            for (int k = tid * 8; k < K; k += NTHR * 8) {
                 const u16x8 v = *(const u16x8*)(x + k);
                 const f32x4 w0 = *(const f32x4*)(p.norm_w + k), w1 = *(const f32x4*)(p.norm_w + k + 4);
                 u16x8 o;
@@ -138,12 +178,13 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
                 *(u16x8*)(xs + k) = o;
             }
         } else {
-            for (int k = tid * 8; k < K; k += 256 * 8) *(uint4*)(xs + k) = *(const uint4*)(x + k);
+            for (int k = tid * 8; k < K; k += NTHR * 8) *(uint4*)(xs + k) = *(const uint4*)(x + k);
         }
+    }
     }
     __syncthreads();
 
-    for (int u = u_first; u < p.units; u += gridDim.x * 4) {
+    for (int u = u_first; u < p.units; u += gridDim.x * NW) {
         float acc[R][MB];
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -188,8 +229,8 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int m = 0; m < MB; ++m) acc[r][m] = wave_sum(acc[r][m]);
-        if (lane == 0) {
+            for (int m = 0; m < MB; ++m) acc[r][m] = wave_sum_lane63(acc[r][m]);     // R x MB reductions per unit: DPP, not LDS shuffles
+        if (lane == 63) {
             if constexpr (FP8) {      // the row's power-of-two scale, once per output
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -230,24 +271,33 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
 
 int g_gemv_variant = 0;   // 0 = production choice; >0 = tuning variants (tools/bench_kernels.py)
 
-template <int MB, int R, int U, bool NT, bool FP8 = false>
+template <int MB, int R, int U, bool NT, bool FP8 = false, int NW = 4>
 int launch_variant(const GemvParams& p0, hipStream_t s, size_t lds) {
     GemvParams p = p0;
     p.units = p.act == VZ_ACT_SWIGLU ? p.N / R : (p.N + R - 1) / R;     // SwiGLU: R/2 outputs of N/2 per unit
-    int blocks = (p.units + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (p.units + NW - 1) / NW;
+    const int cap = NW == 4 ? 2048 : 512;
+    if (blocks > cap) blocks = cap;
     static bool attr = false;
     if (!attr) {
-        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<MB, R, U, NT, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<MB, R, U, NT, FP8, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NW == 4 ? 64 * 1024 : 160 * 1024));
         attr = true;
     }
-    vz_launch_timed(gemv_bf16_kernel<MB, R, U, NT, FP8>, dim3(blocks), dim3(256), lds, s, p);
+    vz_launch_timed(gemv_bf16_kernel<MB, R, U, NT, FP8, NW>, dim3(blocks), dim3(NW * 64), lds, s, p);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
 
 template <int MB>
 int launch_mb(const GemvParams& p, hipStream_t s, size_t lds) {
+    if (lds > 64 * 1024) {        // x does not fit 64 KiB: one 1024-thread workgroup per CU shares one copy (up to 160 KiB)
+        if constexpr (MB >= 2) {
+            if (p.W8) return launch_variant<MB, 2, 8, true, true, 16>(p, s, lds);
+            return launch_variant<MB, 2, 8, true, false, 16>(p, s, lds);
+        } else {
+            return VZ_ERR_ARG;
+        }
+    }
     if (p.W8) {       // 2 rows x up to 8 chunks of 1024 k per wave (measured faster than 4 rows x 4: 13.5 vs 15.3 us on down-proj)
         if (g_gemv_variant == 1) return launch_variant<MB, 4, 4, true, true>(p, s, lds);
         return launch_variant<MB, 2, 8, true, true>(p, s, lds);
@@ -272,7 +322,7 @@ bool vz_gemv_ok(const LinearArgs& a) {
     if (a.W8 && (!a.wscale || (a.ldw & 15) != 0 || ((uintptr_t)a.W8 & 15) != 0)) return false;
     if (a.act == VZ_ACT_SWIGLU && (a.N % 64) != 0) return false;
     const int mb = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
-    return (size_t)mb * a.K * 2 + 64 <= 64 * 1024;
+    return (size_t)mb * a.K * 2 + 256 <= 160 * 1024;
 }
 
 int vz_init_gemv_kernels() {
@@ -303,7 +353,7 @@ int vz_launch_gemv(const LinearArgs& a, hipStream_t s) {
     p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr;
     p.act = a.act; p.out_fp32 = a.out_fp32; p.norm_eps = a.norm_eps; p.units = 0;
     const int mb = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
-    const size_t lds = (size_t)mb * a.K * 2 + 64;
+    const size_t lds = (size_t)mb * a.K * 2 + 256;
     { int r = vz_init_gemv_kernels(); if (r) return r; }
     switch (mb) {
         case 1: return launch_mb<1>(p, s, lds);

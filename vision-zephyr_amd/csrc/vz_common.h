@@ -32,6 +32,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Sum over the 64 lanes with DPP moves (VALU, 4 cycles each) instead of ds_bpermute shuffles (an LDS round trip each): the
+// total is valid in LANE 63 ONLY.  quad swaps, half-row / row mirrors (each 16-lane row then holds its sum in every lane), then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v = dpp_add<0xb1, 0xf>(v);      // quad_perm:[1,0,3,2]
+    v = dpp_add<0x4e, 0xf>(v);      // quad_perm:[2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);     // row_mirror
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 -> rows 1, 3
+    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
