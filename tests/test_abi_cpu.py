@@ -56,3 +56,15 @@ def test_missing_library_is_an_error(tmp_path):
             binding.load_library(str(tmp_path / "nope.so"))
     finally:
         binding._lib = saved
+
+
+def test_graft_entry_abi_assertion_matches_library():
+    """__graft_entry__.build() asserts the ABI version: keep it in step with the library (the driver's build check runs it)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "__graft_entry__.py")).read()
+    want = int(re.search(r"vz_abi_version\(\) == (\d+)", src).group(1))
+    eng = open(os.path.join(root, "vision-zephyr_amd", "csrc", "engine.hip")).read()
+    have = int(re.search(r"vz_abi_version\(void\) \{ return (\d+); \}", eng).group(1))
+    assert want == have
