@@ -328,6 +328,12 @@ def test_batched_generate_and_left_padding(env):
         got = model.generate(input_ids=ids, attention_mask=mask, do_sample=False, max_new_tokens=5, eos_token_id=[stop], pad_token_id=0)
         assert got[1].tolist()[:2] == one_b[0].tolist()[:2] and set(got[1].tolist()[2:]) <= {0}
         assert got[0].tolist() == one_a[0].tolist()
+    # every row hits eos: generation ends at the first step after which all rows are finished (row 0 at step 2, row 1 at step 0)
+    e0, e1 = int(one_a[0, 2]), int(one_b[0, 0])
+    if e0 not in one_a[0, :2].tolist() and e0 not in one_b[0].tolist() and e1 not in one_a[0, :3].tolist():
+        got = model.generate(input_ids=ids, attention_mask=mask, do_sample=False, max_new_tokens=5, eos_token_id=[e0, e1], pad_token_id=0)
+        assert got.shape == (2, 3)
+        assert got[0].tolist() == one_a[0, :3].tolist() and got[1].tolist() == [e1, 0, 0]
     # left padding: roll row 1 to the right edge
     ids_l, mask_l = ids.clone(), mask.clone()
     ids_l[1] = torch.roll(ids[1], 7)

@@ -261,7 +261,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         inputs_embeds, attention_mask, position_ids, _ = self._to_right_padded(inputs_embeds, attention_mask, position_ids)
         seqlens = self._seqlens(attention_mask, Bsz, S)
         if Bsz > 1 and greedy and streamer is None and stopping_criteria is None:
-            return self._generate_batched(inputs_embeds, seqlens, position_ids, max_new_tokens, eos, pad_token_id, sync_every)
+            return self._generate_batched(inputs_embeds, seqlens, position_ids, max_new_tokens, eos, pad_token_id, sync_every, timing)
         outs = []
         for b in range(Bsz):               # per-token host callbacks / sampling: one sequence at a time
             outs.append(self._generate_one(inputs_embeds[b:b + 1, :seqlens[b]],
@@ -274,7 +274,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
             res[b, :len(o)] = torch.tensor(o, dtype=torch.long, device=self.device)
         return res
 
-    def _generate_batched(self, embeds, seqlens, position_ids, max_new, eos, pad_token_id, sync_every) -> torch.Tensor:
+    def _generate_batched(self, embeds, seqlens, position_ids, max_new, eos, pad_token_id, sync_every, timing=None) -> torch.Tensor:
         """Greedy decoding of up to `max_batch` (<= 4) sequences at once: one right-padded prefill, then every decode step
         streams the weights once for all rows (the KV cache, positions and lengths are per slot).  Rows that hit eos keep
         their slot but emit `pad_token_id` from then on, as HF does."""
@@ -298,22 +298,31 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         _, last = eng.prefill(embeds, seqlens, position_ids, all_logits=False, last_logits=True)
         first = B.argmax(last)
         next_pos = [int(seqlens[b]) if position_ids is None else int(position_ids[b, seqlens[b] - 1]) + 1 for b in range(Bsz)]
-        ids = [first.to(torch.long).view(Bsz, 1)]
-        done = torch.tensor([int(t) in eos for t in first.tolist()], dtype=torch.bool)
+        first_cpu = first.to(torch.long).cpu()
+        if timing is not None:
+            import time
+            timing["t_first_token"] = time.perf_counter()        # the host holds every row's first token here
+        cols = [first_cpu.view(Bsz, 1)]
+        eos_t = torch.tensor(sorted(eos), dtype=torch.long)
+        done = torch.isin(first_cpu, eos_t) if eos else torch.zeros(Bsz, dtype=torch.bool)
         eng.decode_begin(first, next_pos, list(seqlens))
         remaining = max_new - 1
         while remaining > 0 and not bool(done.all()):
             n = min(sync_every, remaining) if eos else remaining
-            chunk = eng.decode_steps(n).to(torch.long).cpu()             # [B, n]
+            chunk = eng.decode_steps(n).to(torch.long).cpu()             # [B, n]: the only host sync of the chunk
             remaining -= n
-            for j in range(n):
-                col = chunk[:, j].clone()
-                col[done] = pad_token_id
-                ids.append(col.view(Bsz, 1).to(self.device))
-                done = done | torch.tensor([int(t) in eos for t in chunk[:, j].tolist()]) if eos else done
-                if bool(done.all()):
-                    break
-        return torch.cat([t.to(self.device) for t in ids], dim=1)
+            if eos:
+                hit = torch.isin(chunk, eos_t)                           # eos emitted at (row, step)
+                # a row is finished after its first eos (inclusive): later steps show the pad token
+                after = (torch.cumsum(hit.to(torch.int32), dim=1) - hit.to(torch.int32)) > 0
+                chunk = torch.where(done.view(Bsz, 1) | after, torch.full_like(chunk, pad_token_id), chunk)
+                done_at = done.view(Bsz, 1) | (torch.cumsum(hit.to(torch.int32), dim=1) > 0)      # state after each step
+                all_done = done_at.all(dim=0)
+                if bool(all_done.any()):                                 # stop at the first step after which every row is done
+                    chunk = chunk[:, : int(torch.nonzero(all_done)[0]) + 1]
+                done = done_at[:, chunk.shape[1] - 1]
+            cols.append(chunk)
+        return torch.cat(cols, dim=1).to(self.device)
 
     def _generate_one(self, embeds, position_ids, max_new, greedy, temperature, top_p, top_k, eos, streamer,
                       stopping_criteria, generator, sync_every, timing=None) -> List[int]:
