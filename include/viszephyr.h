@@ -69,7 +69,12 @@ int vz_op_linear(const void* d_A, int lda, const void* d_W, int ldw, void* d_C, 
 int vz_op_linear_fp8(const void* d_A, int lda, const void* d_W8, int ldw, const float* d_wscale, void* d_C, int ldc,
                      int M, int N, int K, const float* d_bias, const void* d_residual, int ldr, int act, int out_fp32,
                      const float* d_norm_w, float norm_eps, vz_stream stream);
-/* same contract, forcing one implementation (tests): impl 0 = MFMA tile GEMM, 1 = GEMV */
+/* x -> bf16(norm_w * x * rsqrt(mean(x^2) + eps)) fused into the staging of the weight-stream kernels (decode: QKV, gate-up,
+ * lm_head; hf:models/mistral/modeling_mistral.py:182-199), then vz_op_linear's contract without bias.  1 <= M <= 16. */
+int vz_op_linear_rmsnorm(const void* d_A, int lda, const float* d_norm_w, float norm_eps, const void* d_W, int ldw, void* d_C, int ldc,
+                         int M, int N, int K, const void* d_residual, int ldr, int act, int out_fp32, vz_stream stream);
+/* same contract, forcing one implementation (tests): impl 0 = 128^2 MFMA tile GEMM, 1 = GEMV (M <= 8), 2 = 256^2 tile GEMM,
+ * 3 = MFMA weight stream for 2 <= M <= 16 (batched decode) */
 int vz_op_linear_impl(int impl, const void* d_A, int lda, const void* d_W, int ldw, void* d_C, int ldc,
                       int M, int N, int K, const float* d_bias, const void* d_residual, int ldr,
                       int act, int out_fp32, vz_stream stream);
@@ -234,7 +239,8 @@ int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_strea
 /* tuning hook for tools/bench_kernels.py: knob 0 = GEMV variant (0 = production choice, 1.. = alternatives
  * compiled into the library: rows per wave, chunks in flight, non-temporal loads), 1 = GEMM kernel choice,
  * 2 = prefill attention generation, 3 = split-K mode, 4 = 256^2 GEMM stream-K tail (1 = on, 0 = whole tiles only), 5 = stream-K skew in K-tiles, 6 = record 256^2 GEMM phase stamps,
- * 7 = route the collectives of a tp_size == 1 engine that holds a one-rank communicator through RCCL (self-test).
+ * 7 = route the collectives of a tp_size == 1 engine that holds a one-rank communicator through RCCL (self-test),
+ * 9 = 2..16-row linears (1 = MFMA weight stream, 0 = GEMV / tile GEMM).
  * Process-wide. */
 int vz_tune_set(int knob, int value);
 

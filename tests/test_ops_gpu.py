@@ -493,3 +493,47 @@ def test_gemv_fp8_rejects_bad_arguments(B):
     w8, scale = quant.quantize_rows(_rand((64, 2048), 0.02, 97))
     with pytest.raises(ValueError):
         B.linear_fp8(_rand((9, 2048), 1.0, 98).bfloat16(), w8, scale)        # M > 8: the fp8 stream is a GEMV
+
+
+# ---- MFMA weight stream for 2..16 activation rows (batched decode; gemm_skinny.hip) ----
+@pytest.mark.parametrize("M,N,K,act", [(2, 6144, 4096, 0), (4, 4096, 14336, 0), (4, 28672, 4096, 3), (8, 4096, 4096, 0), (16, 6144, 4096, 0),
+                                       (16, 2048, 14336, 0), (3, 32001, 4096, 0), (5, 257, 1024, 0), (7, 64, 512, 3), (16, 1024, 576, 0)])
+def test_skinny_gemm(B, M, N, K, act):
+    """one 16x16x32 MFMA per KiB of weights for all rows: results must match the fp64 reference like the GEMV does (fp32
+    accumulation, one bf16 rounding), through bias / activation / SwiGLU / residual / fp32 output, ragged N included."""
+    x = _rand((M, K), 1.0, 100).bfloat16()
+    w = _rand((N, K), 0.03, 101).bfloat16()
+    n_out = N // 2 if act == 3 else N
+    res = _rand((M, n_out), 1.0, 102).bfloat16()
+    bias = None if act == 3 else _rand((N,), 0.3, 103)
+    out = B.linear(x, w, bias=bias, residual=res, act=act, impl=3)
+    check_close(f"skinny {M}x{N}x{K} act{act}", out, _ref_linear(x, w, bias, res, act), BF16_MAX, BF16_L2)
+    out32 = B.linear(x, w, act=act, out_fp32=True, impl=3)
+    check_close(f"skinny fp32 {M}x{N}x{K} act{act}", out32, _ref_linear(x, w, None, None, act), 1e-4, 1e-4)
+    # rows are independent: every row equals what it gets in a 2-row launch (batch invariance of the decode path)
+    pair = B.linear(x[:2].contiguous(), w, act=act, out_fp32=True, impl=3)
+    assert torch.equal(pair, out32[:2])
+    # the production dispatch takes this path for 2..16 rows
+    assert torch.equal(B.linear(x, w, act=act, out_fp32=True), out32)
+
+
+@pytest.mark.parametrize("M,act", [(2, 0), (4, 3), (9, 0), (16, 3)])
+def test_skinny_gemm_fused_rmsnorm(B, M, act):
+    K, N = 4096, 6144
+    x = _rand((M, K), 3.0, 104).bfloat16()
+    nw = _rand((K,), 0.2, 105) + 1.0
+    w = _rand((N, K), 0.02, 106).bfloat16()
+    xf = bf16r(x).double()
+    xn = (nw.double() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))).float().bfloat16()
+    out = B.linear_rmsnorm(x, nw, 1e-5, w, act=act, out_fp32=True)
+    check_close(f"skinny fused rmsnorm M{M} act{act}", out, _ref_linear(xn, w, None, None, act), 2e-2, 3e-3)
+    # exactly the stand-alone norm kernel followed by the same GEMM
+    assert torch.equal(out, B.linear(B.rmsnorm(x, nw, 1e-5), w, act=act, out_fp32=True, impl=3))
+    # and, with the knob off, the GEMV path fuses the norm the same way (M <= 8)
+    if M <= 8:
+        try:
+            B.check(B.lib().vz_tune_set(9, 0))
+            gv = B.linear_rmsnorm(x, nw, 1e-5, w, act=act, out_fp32=True)
+        finally:
+            B.check(B.lib().vz_tune_set(9, 1))
+        check_close(f"gemv vs skinny fused norm M{M}", gv, out, 1e-4, 1e-4)

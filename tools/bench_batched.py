@@ -28,9 +28,9 @@ def build(max_batch):
     return VisZephyrForCausalLM.from_synthetic(hf, seed=0, device="cuda:0", max_batch=max_batch, max_ctx=512, max_tiles=1, max_text=64)
 
 
-model = build(4)
+model = build(16)
 n_new = 64
-for B in (1, 2, 4):
+for B in (1, 2, 4, 8, 16):
     ids = torch.stack([synth.synth_ids(64, 32000, image_pos=-1, seed=10 + b) for b in range(B)]).cuda()
     model.generate(input_ids=ids, do_sample=False, max_new_tokens=n_new, eos_token_id=None, pad_token_id=2)
     torch.cuda.synchronize()

@@ -129,6 +129,29 @@ def bench_preprocess():
               f"host PIL + CLIPImageProcessor {cpu_us:9.1f} us  ({cpu_us / us:6.1f}x)", flush=True)
 
 
+def bench_skinny():
+    """2..16 activation rows through the decode linears: MFMA weight stream (gemm_skinny.hip) vs the GEMV (M <= 8) / tile GEMM."""
+    shapes = [("qkv", 6144, 4096, 0), ("o", 4096, 4096, 0), ("gate-up swiglu", 28672, 4096, 3), ("down", 4096, 14336, 0)]
+    for name, N, K, act in shapes:
+        pool = max(2, int(1.0e9 // (N * K * 2)))
+        ws = [torch.randn(N, K, device=dev).bfloat16() * 0.02 for _ in range(pool)]
+        row = []
+        for M in (1, 2, 4, 8, 16):
+            x = torch.randn(M, K, device=dev).bfloat16()
+            us = {}
+            for mode in (1, 0):
+                B.check(B.lib().vz_tune_set(9, mode))
+                us[mode] = min(timed(lambda i: B.linear(x, ws[i % pool], act=act), 4 * pool) for _ in range(3))
+            B.check(B.lib().vz_tune_set(9, 1))
+            row.append(f"M{M}: {us[1]:6.1f} (was {us[0]:6.1f}) us")
+            if K == 4096 and name != "o":      # the decode step fuses the RMSNorm into these
+                nw = torch.ones(K, device=dev)
+                usn = min(timed(lambda i: B.linear_rmsnorm(x, nw, 1e-5, ws[i % pool], act=act), 4 * pool) for _ in range(3))
+                row[-1] += f" [+norm {usn:6.1f}]"
+        print(f"skinny {name:15s} {N * K * 2 / 1e6:6.1f} MB: " + "  ".join(row), flush=True)
+        del ws
+
+
 def bench_gemv_resident():
     """Does a GEMV run faster when its weights sit in the 256 MiB Infinity Cache (read by the previous kernel) than from
     HBM?  Same weights every launch (resident) vs a pool larger than the cache (streamed), per shape."""
@@ -246,6 +269,8 @@ if __name__ == "__main__":
         bench_gemm()
     if what == "preprocess":
         bench_preprocess()
+    if what == "skinny":
+        bench_skinny()
     if what == "gemv8":
         bench_gemv_fp8()
     if what == "gemvres":

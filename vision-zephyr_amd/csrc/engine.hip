@@ -64,6 +64,14 @@ extern "C" int vz_op_linear_fp8(const void* A, int lda, const void* W8, int ldw,
     a.W8 = (const unsigned char*)W8; a.wscale = wscale; a.norm_w = norm_w; a.norm_eps = norm_eps;
     return vz_launch_gemv(a, (hipStream_t)s);
 }
+extern "C" int vz_op_linear_rmsnorm(const void* A, int lda, const float* norm_w, float norm_eps, const void* W, int ldw, void* C, int ldc,
+                                    int M, int N, int K, const void* residual, int ldr, int act, int out_fp32, vz_stream s) {
+    VZ_CHECK_ARG(norm_w && M >= 1 && M <= 16, "linear_rmsnorm: needs norm weights and 1 <= M <= 16 (the fused norm lives on the weight-stream kernels)");
+    LinearArgs a = mk_linear(A, lda, W, ldw, C, ldc, M, N, K, nullptr, residual, ldr, act, out_fp32);
+    a.norm_w = norm_w; a.norm_eps = norm_eps;
+    VZ_CHECK_ARG((g_skinny_mode && vz_skinny_ok(a)) || vz_gemv_ok(a), "linear_rmsnorm: shape M=%d K=%d not supported by the weight-stream kernels", M, K);
+    return vz_launch_linear(a, (hipStream_t)s);
+}
 extern "C" int vz_op_linear_impl(int impl, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N,
                                  int K, const float* bias, const void* residual, int ldr, int act, int out_fp32,
                                  vz_stream s) {
@@ -71,6 +79,7 @@ extern "C" int vz_op_linear_impl(int impl, const void* A, int lda, const void* W
     if (impl == 0) return vz_launch_gemm128(a, (hipStream_t)s);
     if (impl == 1) return vz_launch_gemv(a, (hipStream_t)s);
     if (impl == 2) return vz_launch_gemm256(a, (hipStream_t)s);
+    if (impl == 3) return vz_launch_skinny(a, (hipStream_t)s);
     vz_set_error("linear: unknown impl %d", impl);
     return VZ_ERR_ARG;
 }
@@ -150,6 +159,7 @@ struct vz_engine {
     int* d_state = nullptr;  // [cur_ids[B] | pos[B] | slot[B] | len[B] | step]
     int dec_B = 0;
     float* d_logits = nullptr;   // [max_batch, vocab] fp32
+    bf16_t* d_xnorm = nullptr;   // [16, hidden]: normalised rows of a 5..16-row decode batch (the MFMA weight stream reads them from L2)
     float* d_part = nullptr;     // decode attention partials
     unsigned* d_ticket = nullptr; // arrival counters of the fused decode attention
     int nsplit = 16;
@@ -219,8 +229,16 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
         a.W8 = W8; a.wscale = ws;
         if (!vz_gemv_ok(a)) { a.W8 = nullptr; a.wscale = nullptr; }
     }
-    if (norm_w) { ProfScope ps(e, K_GEMV, s); return vz_launch_gemv(a, s); }
-    const bool gemv = vz_gemv_ok(a);
+    if (norm_w && M > 4 && K == e->c.hidden && g_skinny_mode && !a.W8) {
+        // 5..16 rows: staging the normalised rows in LDS (M x 8 KiB) would leave one workgroup per CU; normalise once into
+        // an L2-resident scratch instead and let the MFMA weight stream take its B fragments from there
+        { ProfScope ps(e, K_NORM, s); int r = vz_launch_rmsnorm(A, lda, e->d_xnorm, K, norm_w, M, K, norm_eps, s); if (r) return r; }
+        a.A = e->d_xnorm; a.lda = K; a.norm_w = nullptr;
+        if (vz_skinny_ok(a)) { ProfScope ps(e, K_GEMV, s); return vz_launch_skinny(a, s); }
+        a.A = A; a.lda = lda; a.norm_w = norm_w;
+    }
+    if (norm_w) { ProfScope ps(e, K_GEMV, s); return vz_launch_linear(a, s); }     // skinny MFMA stream or GEMV: both fuse the norm
+    const bool gemv = vz_gemv_ok(a) || (g_skinny_mode && vz_skinny_ok(a));
     ProfScope ps(e, gemv ? K_GEMV : K_GEMM, s);
     (void)klass_hint;
     return vz_launch_linear(a, s);
@@ -289,6 +307,7 @@ extern "C" int vz_engine_create(const vz_config* cfg, vz_engine** out) {
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_logits, (size_t)c.max_batch * e->Vp * e->tp * sizeof(float));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_part, (size_t)c.max_batch * e->Hkv_l * 64 * (4 * 128 + 32) * sizeof(float));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_ticket, 4096);
+    if (er == hipSuccess) er = hipMalloc((void**)&e->d_xnorm, (size_t)16 * c.hidden * sizeof(bf16_t));
     if (er == hipSuccess) er = hipMemset(e->d_ticket, 0, 4096);
     if (er != hipSuccess) {
         vz_set_error("engine_create: hipMalloc failed: %s", hipGetErrorString(er));
@@ -311,6 +330,7 @@ extern "C" int vz_engine_destroy(vz_engine* e) {
     if (e->d_logits) hipFree(e->d_logits);
     if (e->d_part) hipFree(e->d_part);
     if (e->d_ticket) hipFree(e->d_ticket);
+    if (e->d_xnorm) hipFree(e->d_xnorm);
     if (e->d_gather) (void)hipFree(e->d_gather);
     if (e->comm) (void)ncclCommDestroy(e->comm);
     if (e->h_pinned) hipHostFree(e->h_pinned);
@@ -757,7 +777,7 @@ extern "C" int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, 
     NEED_READY();
     const vz_config& c = e->c;
     hipStream_t s = (hipStream_t)stream;
-    VZ_CHECK_ARG(B >= 1 && B <= c.max_batch && B <= 4 && d_first_ids && h_next_pos && h_ctx_len, "decode_begin: B=%d unsupported (1..min(4,max_batch))", B);
+    VZ_CHECK_ARG(B >= 1 && B <= c.max_batch && B <= 16 && d_first_ids && h_next_pos && h_ctx_len, "decode_begin: B=%d unsupported (1..min(16,max_batch))", B);
     const int mb = c.max_batch;
     std::vector<int> h(3 * mb + 4, 0);
     for (int b = 0; b < B; ++b) {
@@ -870,6 +890,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 5) { g_gemm256_skew = value; return VZ_OK; }
     if (knob == 6) { g_gemm256_stamps = value; return VZ_OK; }
     if (knob == 7) { g_force_comm = value; return VZ_OK; }
+    if (knob == 9) { g_skinny_mode = value; return VZ_OK; }
     vz_set_error("tune_set: unknown knob %d", knob);
     return VZ_ERR_ARG;
 }

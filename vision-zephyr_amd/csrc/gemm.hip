@@ -327,7 +327,7 @@ int vz_init_gemm_kernels() {
         g_slab_bytes = (size_t)96 << 20;
     }
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-    { int r = vz_init_gemv_kernels(); if (r) return r; r = vz_init_gemm256_kernel(); if (r) return r; }
+    { int r = vz_init_gemv_kernels(); if (r) return r; r = vz_init_gemm256_kernel(); if (r) return r; r = vz_init_skinny_kernels(); if (r) return r; }
     done = true;
     return VZ_OK;
 }
@@ -397,6 +397,7 @@ int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
 }
 
 int vz_launch_linear(const LinearArgs& a, hipStream_t s) {
+    if (g_skinny_mode && vz_skinny_ok(a)) return vz_launch_skinny(a, s);      // 2..16 rows (batched decode): one MFMA per KiB of weights
     if (vz_gemv_ok(a)) return vz_launch_gemv(a, s);
     return vz_launch_gemm(a, s);
 }

@@ -1,0 +1,239 @@
+// Weight-streaming MFMA GEMM for 2..16 activation rows (batched decode): C[M<=16, N'] = epi(x[M,K] . W[N,K]^T).
+//
+// The GEMV (gemv.hip) multiplies every weight by every activation row on the VALU: v_dot2c work per weight byte grows
+// with M and a 4-row launch already takes 1.4x a 1-row launch.  Here the 16 x 16 x 32 MFMA takes a 16-row x 32-k weight
+// tile as its A operand and ALL activation rows (padded to 16) as its B operand: one matrix instruction per KiB of
+// weights whatever M is, no cross-lane reduction (lane (m, g) of the result holds outputs n = 4g..4g+3 of row m), and the
+// kernel stays a pure HBM stream up to 16 rows.
+//
+//   * workgroup = 8 waves = one group of 16 weight rows (SwiGLU: the 16 gate + 16 up rows of one interleaved group) over
+//     the whole K; wave w streams the contiguous K-slice w, so the 256 row groups of a 4096-row projection still put 2048
+//     waves on the chip; the eight partial tiles meet in LDS (8 KiB) and wave 0 runs the epilogue.
+//   * a step is 64 k = two MFMAs: lane (row r, g) loads the 32 contiguous bytes W[r][64s + 16g .. 64s + 16g + 15] - four
+//     lanes take one whole 128-byte line, every line is requested once - and feeds k = 16g..16g+7 to the first MFMA,
+//     16g+8..16g+15 to the second; the activation fragments use the same k assignment, which is all the contraction needs.
+//   * activations: with a fused RMSNorm (QKV, gate-up, lm_head: K = hidden) the normalised rows are staged once per
+//     workgroup in LDS (one wave per row, row stride K + 8 elements: conflict-free fragment reads); without it (O-proj,
+//     down-proj) the B fragments are loaded straight from global memory - x is at most 16 x 14336 bf16 = 448 KiB, L2
+//     resident, and rides in the same prefetch ring as the weights.
+#include "vz_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// NW = waves per workgroup = K-slices of one row group: 8 while the projection has fewer than 512 row groups (4096 rows = 256
+// groups -> 2048 waves), 4 beyond (gate-up: 896 groups fit the chip in ONE round of 4-wave workgroups instead of 1.75 rounds of
+// 8-wave ones)
+// 64-k steps in flight per wave (32 B per lane and operand each): sized so that every variant stays under 128 VGPRs = two
+// 8-wave workgroups per CU
+template <bool SWIGLU, bool NORM> struct Depth { static constexpr int U = (SWIGLU || !NORM) ? 4 : 8; };
+
+struct SkinnyParams {
+    const bf16_t* A; const bf16_t* W; void* C;
+    const float* bias; const bf16_t* residual; const float* norm_w;
+    int M, N, K, lda, ldw, ldc, ldr;
+    int act, out_fp32;
+    float norm_eps;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == VZ_ACT_QUICK_GELU) return act_quick_gelu(v);
+    if (act == VZ_ACT_GELU_ERF) return act_gelu_erf(v);
+    return v;
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <bool SWIGLU, bool NORM, int NW>
+__global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int K = p.K;
+    const int xs_stride = K + 8;                                          // elements; 16 extra bytes per row: no bank conflicts
+    bf16_t* xs = (bf16_t*)smem;                                           // NORM: [M][K + 8]
+    float* red = (float*)(smem + (NORM ? (size_t)p.M * xs_stride * 2 : 0));  // [NW][2][64][4]
+
+    // ---- weight rows of this workgroup ----
+    const int grp = blockIdx.x;
+    int row_a, row_b = 0;                                                  // row this lane streams (tile a; SwiGLU: tile b = up)
+    if (SWIGLU) { row_a = grp * 32 + fr; row_b = row_a + 16; }
+    else { row_a = grp * 16 + fr; row_a = row_a < p.N ? row_a : p.N - 1; }
+    const bf16_t* wa = p.W + (size_t)row_a * p.ldw + g * 16;
+    const bf16_t* wb = p.W + (size_t)row_b * p.ldw + g * 16;
+
+    // ---- this wave's K-slice, in steps of 64 k ----
+    constexpr int U = Depth<SWIGLU, NORM>::U;
+    const int steps = K >> 6;
+    const int per = (steps + NW - 1) / NW;
+    const int s0 = wave * per < steps ? wave * per : steps;
+    const int s1 = s0 + per < steps ? s0 + per : steps;
+
+    u32x4 qa[U][2], qb[U][2], qx[U][2];
+    const bool row_ok = fr < p.M;
+    const bf16_t* xg = p.A + (size_t)(row_ok ? fr : 0) * p.lda + g * 16;   // !NORM: B fragments straight from global / L2
+    auto issue = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = i0 + u;
+            if (s < s1) {
+                const u32x4* pa = (const u32x4*)(wa + (size_t)s * 64);
+                qa[u][0] = pa[0]; qa[u][1] = pa[1];        // default cache policy: the two halves of a line are requested by two instructions
+                if (SWIGLU) {
+                    const u32x4* pb = (const u32x4*)(wb + (size_t)s * 64);
+                    qb[u][0] = pb[0]; qb[u][1] = pb[1];
+                }
+                if (!NORM) {
+                    const u32x4* px = (const u32x4*)(xg + (size_t)s * 64);
+                    qx[u][0] = row_ok ? px[0] : (u32x4){0u, 0u, 0u, 0u};
+                    qx[u][1] = row_ok ? px[1] : (u32x4){0u, 0u, 0u, 0u};
+                }
+            }
+        }
+    };
+    issue(s0);          // the first weights are in flight before the norm prologue
+
+    if (NORM) {         // one wave per activation row (rows m = wave, wave + NW, ...): bf16(norm_w * x * rstd) -> LDS
+        for (int m = wave; m < p.M; m += NW) {
+            const bf16_t* x = p.A + (size_t)m * p.lda;
+            float ss = 0.f;
+            for (int k = lane * 8; k < K; k += 64 * 8) {
+                const u16x8 v = *(const u16x8*)(x + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(v[j]); ss += f * f; }
+            }
+            const float rstd = rsqrtf(wave_sum(ss) / (float)K + p.norm_eps);
+            for (int k = lane * 8; k < K; k += 64 * 8) {
+                const u16x8 v = *(const u16x8*)(x + k);
+                const f32x4 w0 = *(const f32x4*)(p.norm_w + k), w1 = *(const f32x4*)(p.norm_w + k + 4);
+                u16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float wj = j < 4 ? w0[j] : w1[j - 4];
+                    o[j] = f32_to_bf16(wj * (bf16_to_f32(v[j]) * rstd));
+                }
+                *(u16x8*)(xs + (size_t)m * xs_stride + k) = o;
+            }
+        }
+        __syncthreads();
+    }
+
+    f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+    const bf16_t* xl = xs + (size_t)(row_ok ? fr : 0) * xs_stride + g * 16;
+    for (int i0 = s0; i0 < s1; i0 += U) {
+        if (i0 != s0) issue(i0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = i0 + u;
+            if (s < s1) {
+                u32x4 x0, x1;
+                if (NORM) {
+                    const u32x4* px = (const u32x4*)(xl + (size_t)s * 64);
+                    x0 = row_ok ? px[0] : (u32x4){0u, 0u, 0u, 0u};
+                    x1 = row_ok ? px[1] : (u32x4){0u, 0u, 0u, 0u};
+                } else {
+                    x0 = qx[u][0]; x1 = qx[u][1];
+                }
+                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qa[u][0]), as_bf16x8(x0), acc_a, 0, 0, 0);
+                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qa[u][1]), as_bf16x8(x1), acc_a, 0, 0, 0);
+                if (SWIGLU) {
+                    acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qb[u][0]), as_bf16x8(x0), acc_b, 0, 0, 0);
+                    acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qb[u][1]), as_bf16x8(x1), acc_b, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- the eight K-slices meet in LDS; wave 0 finishes: lane (m = fr, g) holds outputs n = 4g..4g+3 of row m ----
+    *(f32x4*)(red + ((size_t)(wave * 2 + 0) * 64 + lane) * 4) = acc_a;
+    if (SWIGLU) *(f32x4*)(red + ((size_t)(wave * 2 + 1) * 64 + lane) * 4) = acc_b;
+    __syncthreads();
+    if (wave != 0 || !row_ok) return;
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        sa += *(const f32x4*)(red + ((size_t)(w * 2 + 0) * 64 + lane) * 4);
+        if (SWIGLU) sb += *(const f32x4*)(red + ((size_t)(w * 2 + 1) * 64 + lane) * 4);
+    }
+    const int m = fr;
+    const int n_out_total = SWIGLU ? p.N / 2 : p.N;
+    const int n0 = grp * 16 + g * 4;                  // output column (SwiGLU: group j of 16 outputs = packed rows 32j..32j+31)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j;
+        if (n >= n_out_total) break;
+        float t;
+        if (SWIGLU) {
+            t = act_silu(sa[j]) * sb[j];
+        } else {
+            t = sa[j];
+            if (p.bias) t += p.bias[n];
+            t = apply_act(t, p.act);
+        }
+        if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + n]);
+        if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + n] = t;
+        else ((bf16_t*)p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(t);
+    }
+}
+
+size_t skinny_lds(const LinearArgs& a) {
+    return (a.norm_w ? (size_t)a.M * (a.K + 8) * 2 : 0) + (size_t)8 * 2 * 64 * 4 * sizeof(float);
+}
+
+template <bool SWIGLU, bool NORM, int NW>
+int launch_nw(const SkinnyParams& p, int blocks, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_kernel<SWIGLU, NORM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    vz_launch_timed(skinny_kernel<SWIGLU, NORM, NW>, dim3(blocks), dim3(NW * 64), lds, s, p);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
+template <bool SWIGLU, bool NORM>
+int launch(const SkinnyParams& p, int blocks, size_t lds, hipStream_t s) {
+    if (blocks >= 512 && (p.K >> 6) >= 16) return launch_nw<SWIGLU, NORM, 4>(p, blocks, lds, s);
+    return launch_nw<SWIGLU, NORM, 8>(p, blocks, lds, s);
+}
+
+}  // namespace
+
+int g_skinny_mode = 1;   // vz_tune_set(9, v): 1 = 2..16-row linears use the MFMA weight stream (default), 0 = GEMV / tile GEMM as before
+
+bool vz_skinny_ok(const LinearArgs& a) {
+    if (a.M < 2 || a.M > 16 || a.W8 || (a.K & 63) != 0 || a.K < 512) return false;
+    if (a.act == VZ_ACT_SWIGLU && (a.N % 32) != 0) return false;
+    if ((a.lda & 7) != 0 || (a.ldw & 7) != 0) return false;                       // 16-byte fragment loads
+    return skinny_lds(a) <= 160 * 1024;
+}
+
+int vz_init_skinny_kernels() {
+    static bool done = false;
+    if (done) return VZ_OK;
+    // every variant a captured decode step can reach gets its dynamic-LDS limit now (never inside a stream capture)
+#define VZ_SK_ATTR(SW, NM, W) VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_kernel<SW, NM, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VZ_SK_ATTR(false, false, 4) VZ_SK_ATTR(false, false, 8) VZ_SK_ATTR(false, true, 4) VZ_SK_ATTR(false, true, 8)
+    VZ_SK_ATTR(true, false, 4) VZ_SK_ATTR(true, false, 8) VZ_SK_ATTR(true, true, 4) VZ_SK_ATTR(true, true, 8)
+#undef VZ_SK_ATTR
+    done = true;
+    return VZ_OK;
+}
+
+int vz_launch_skinny(const LinearArgs& a, hipStream_t s) {
+    int rc = vz_linear_check_common(a);
+    if (rc) return rc;
+    VZ_CHECK_ARG(vz_skinny_ok(a), "skinny gemm: needs 2 <= M <= 16, bf16 weights, K %% 64 == 0 and >= 512, 16-byte-aligned rows (M=%d K=%d)", a.M, a.K);
+    { int r = vz_init_skinny_kernels(); if (r) return r; }
+    SkinnyParams p;
+    p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.residual = a.residual; p.norm_w = a.norm_w;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr;
+    p.act = a.act; p.out_fp32 = a.out_fp32; p.norm_eps = a.norm_eps;
+    const bool sw = a.act == VZ_ACT_SWIGLU;
+    const int blocks = sw ? a.N / 32 : (a.N + 15) / 16;
+    const size_t lds = skinny_lds(a);
+    if (sw) return a.norm_w ? launch<true, true>(p, blocks, lds, s) : launch<true, false>(p, blocks, lds, s);
+    return a.norm_w ? launch<false, true>(p, blocks, lds, s) : launch<false, false>(p, blocks, lds, s);
+}

@@ -103,6 +103,10 @@ struct LinearArgs {
 int vz_launch_gemm(const LinearArgs& a, hipStream_t s);
 int vz_linear_check_common(const LinearArgs& a);
 bool vz_gemv_ok(const LinearArgs& a);
+bool vz_skinny_ok(const LinearArgs& a);      // 2..16 rows: MFMA weight stream (gemm_skinny.hip)
+int vz_launch_skinny(const LinearArgs& a, hipStream_t s);
+int vz_init_skinny_kernels();
+extern int g_skinny_mode;
 int vz_init_gemv_kernels();
 void vz_set_gemv_variant(int v);
 // Profiling: when set, the next GEMM/GEMV launch is issued through hipExtLaunchKernelGGL with these events, which

@@ -275,12 +275,12 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         return res
 
     def _generate_batched(self, embeds, seqlens, position_ids, max_new, eos, pad_token_id, sync_every, timing=None) -> torch.Tensor:
-        """Greedy decoding of up to `max_batch` (<= 4) sequences at once: one right-padded prefill, then every decode step
+        """Greedy decoding of up to `max_batch` (<= 16) sequences at once: one right-padded prefill, then every decode step
         streams the weights once for all rows (the KV cache, positions and lengths are per slot).  Rows that hit eos keep
         their slot but emit `pad_token_id` from then on, as HF does."""
         eng = self.engine
         Bsz, S = embeds.shape[0], embeds.shape[1]
-        cap = min(eng.max_batch, 4)
+        cap = min(eng.max_batch, 16)
         if Bsz > cap:
             parts = [self._generate_batched(embeds[i:i + cap], seqlens[i:i + cap],
                                             None if position_ids is None else position_ids[i:i + cap], max_new, eos,

@@ -67,6 +67,7 @@ SYMBOLS = {
     "vz_engine_resize_vocab": (_I, [_P, _I]),
     "vz_op_resample_u8": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P]),
     "vz_op_anyres_tiles": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "vz_op_linear_rmsnorm": (_I, [_P, _I, _P, _F, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     "vz_op_linear_fp8": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _F, _P]),
     "vz_tp_all_gather": (_I, [_P, _P, _P, C.c_size_t, _P]),
     "vz_prof_enable": (_I, [_P, _I, _I]),
@@ -153,6 +154,20 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: int 
         check(lib().vz_op_linear(*args))
     else:
         check(lib().vz_op_linear_impl(impl, *args))
+    return out
+
+
+def linear_rmsnorm(x: torch.Tensor, norm_w: torch.Tensor, eps: float, w: torch.Tensor, residual=None, act: int = ACT_NONE,
+                   out_fp32=False) -> torch.Tensor:
+    """epi(rmsnorm(x) @ w^T) with the norm fused into the weight-stream kernel's staging; M <= 16."""
+    _need_cuda(x, w, norm_w, residual)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and norm_w.dtype == torch.float32
+    M, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    out = torch.empty(M, n_out, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=x.device)
+    check(lib().vz_op_linear_rmsnorm(ptr(x), x.stride(0), ptr(norm_w), float(eps), ptr(w), w.stride(0), ptr(out), out.stride(0), M, N, K,
+                                     ptr(residual), 0 if residual is None else residual.stride(0), act, int(out_fp32), stream_ptr(x.device)))
     return out
 
 
