@@ -441,7 +441,8 @@ def test_gemm_splitk_small_m(B, M, N, K, act):
 
 # ---- W8A16 weight stream (SURVEY config 5): e4m3 rows + one power-of-two scale per row ----
 @pytest.mark.parametrize("M,N,K,act", [(1, 6144, 4096, 0), (1, 4096, 14336, 0), (1, 28672, 4096, 3), (2, 4096, 4096, 0),
-                                       (4, 1024, 4096, 0), (8, 2048, 2048, 3), (1, 32001, 4096, 0), (3, 257, 1024, 0)])
+                                       (4, 1024, 4096, 0), (8, 2048, 2048, 3), (1, 32001, 4096, 0), (3, 257, 1024, 0),
+                                       (16, 28672, 4096, 3), (11, 4096, 14336, 0)])
 def test_gemv_fp8_weights(B, M, N, K, act):
     """The fp8 GEMV must equal the dot product with the DEQUANTISED weights (2^e * e4m3, exact in bf16) to fp32
     accumulation accuracy, through every epilogue; and the dequantised bf16 weights through the bf16 GEMV must give the
@@ -458,11 +459,18 @@ def test_gemv_fp8_weights(B, M, N, K, act):
     n_out = N // 2 if act == 3 else N
     res = _rand((M, n_out), 1.0, 92).bfloat16()
     bias = None if act == 3 else _rand((N,), 0.3, 93)
-    out32 = B.linear_fp8(x, w8, scale, act=act, out_fp32=True)
-    check_close(f"gemv fp8 fp32 {M}x{N}x{K} act{act}", out32, _ref_linear(x, wq, None, None, act), 1e-4, 1e-4)
-    out = B.linear_fp8(x, w8, scale, bias=bias, residual=res, act=act)
-    check_close(f"gemv fp8 {M}x{N}x{K} act{act}", out, _ref_linear(x, wq, bias, res, act), BF16_MAX, BF16_L2)
-    same = B.linear(x, wq.bfloat16(), bias=bias, residual=res, act=act, impl=1)
+    for mode in (1, 0):          # 2..16 rows: MFMA weight stream (gemm_skinny.hip) / the GEMV form (M <= 8); 1 row: always the GEMV
+        if mode == 0 and M > 8:
+            continue
+        try:
+            B.check(B.lib().vz_tune_set(9, mode))
+            out32 = B.linear_fp8(x, w8, scale, act=act, out_fp32=True)
+            out = B.linear_fp8(x, w8, scale, bias=bias, residual=res, act=act)
+        finally:
+            B.check(B.lib().vz_tune_set(9, 1))
+        check_close(f"fp8 fp32 {M}x{N}x{K} act{act} mode{mode}", out32, _ref_linear(x, wq, None, None, act), 1e-4, 1e-4)
+        check_close(f"fp8 {M}x{N}x{K} act{act} mode{mode}", out, _ref_linear(x, wq, bias, res, act), BF16_MAX, BF16_L2)
+    same = B.linear(x, wq.bfloat16(), bias=bias, residual=res, act=act, impl=1 if M <= 8 else 3)
     # identical products and the same fp32 accumulation order per lane would make these bit-equal; the lane -> k mapping
     # differs (16 vs 8 weights per lane), so allow fp32 re-association: at most one bf16 step on a handful of outputs
     assert float((out.float() - same.float()).abs().max()) <= 2 ** -7 * float(same.float().abs().max()) + 1e-6
@@ -492,7 +500,7 @@ def test_gemv_fp8_rejects_bad_arguments(B):
         B.linear_fp8(_rand((1, 1536), 1.0, 98).bfloat16(), w8, scale)        # K not a multiple of 1024
     w8, scale = quant.quantize_rows(_rand((64, 2048), 0.02, 97))
     with pytest.raises(ValueError):
-        B.linear_fp8(_rand((9, 2048), 1.0, 98).bfloat16(), w8, scale)        # M > 8: the fp8 stream is a GEMV
+        B.linear_fp8(_rand((17, 2048), 1.0, 98).bfloat16(), w8, scale)       # M > 16: the fp8 stream serves decode batches only
 
 
 # ---- MFMA weight stream for 2..16 activation rows (batched decode; gemm_skinny.hip) ----

@@ -17,6 +17,9 @@ layers = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 import bench  # noqa: E402
 
 
+FP8 = len(sys.argv) > 2 and sys.argv[2] == "fp8"
+
+
 def build(max_batch):
     from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
     hf = VisZephyrConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=layers, num_attention_heads=32,
@@ -25,7 +28,8 @@ def build(max_batch):
     hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
     hf.mm_patch_merge_type = "flat"
     hf.mm_hidden_size = 5120
-    return VisZephyrForCausalLM.from_synthetic(hf, seed=0, device="cuda:0", max_batch=max_batch, max_ctx=512, max_tiles=1, max_text=64)
+    return VisZephyrForCausalLM.from_synthetic(hf, seed=0, device="cuda:0", max_batch=max_batch, max_ctx=512, max_tiles=1, max_text=64,
+                                               weight_fp8=FP8)
 
 
 model = build(16)
@@ -43,4 +47,4 @@ for B in (1, 2, 4, 8, 16):
         t1 = time.perf_counter()
         best = min(best, t1 - tm.get("t_first_token", t0))
     assert tuple(out.shape) == (B, n_new)
-    print(f"batch {B}: {B * (n_new - 1) / best:8.1f} decode tokens/s total ({(n_new - 1) / best:7.1f} per sequence), {best / (n_new - 1) * 1e3:6.3f} ms per step", flush=True)
+    print(f"{'fp8 ' if FP8 else ''}batch {B}: {B * (n_new - 1) / best:8.1f} decode tokens/s total ({(n_new - 1) / best:7.1f} per sequence), {best / (n_new - 1) * 1e3:6.3f} ms per step", flush=True)

@@ -62,7 +62,7 @@ extern "C" int vz_op_linear_fp8(const void* A, int lda, const void* W8, int ldw,
     VZ_CHECK_ARG(W8 && wscale, "linear_fp8: null weights / scales");
     LinearArgs a = mk_linear(A, lda, (const void*)W8, ldw, C, ldc, M, N, K, bias, residual, ldr, act, out_fp32);
     a.W8 = (const unsigned char*)W8; a.wscale = wscale; a.norm_w = norm_w; a.norm_eps = norm_eps;
-    return vz_launch_gemv(a, (hipStream_t)s);
+    return vz_launch_linear(a, (hipStream_t)s);      // 1 row: GEMV; 2..16 rows: MFMA weight stream (gemm_skinny.hip)
 }
 extern "C" int vz_op_linear_rmsnorm(const void* A, int lda, const float* norm_w, float norm_eps, const void* W, int ldw, void* C, int ldc,
                                     int M, int N, int K, const void* residual, int ldr, int act, int out_fp32, vz_stream s) {
@@ -225,11 +225,11 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
                   const float* norm_w = nullptr, float norm_eps = 0.f, const unsigned char* W8 = nullptr, const float* ws = nullptr) {
     LinearArgs a = mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, res, ldr, act, out_fp32);
     a.norm_w = norm_w; a.norm_eps = norm_eps;
-    if (W8 && ws) {                       // e4m3 copy of the same weights: only the GEMV streams it
+    if (W8 && ws) {                       // e4m3 copy of the same weights: only the weight-stream kernels (M <= 16) take it
         a.W8 = W8; a.wscale = ws;
-        if (!vz_gemv_ok(a)) { a.W8 = nullptr; a.wscale = nullptr; }
+        if (!vz_gemv_ok(a) && !(g_skinny_mode && vz_skinny_ok(a))) { a.W8 = nullptr; a.wscale = nullptr; }
     }
-    if (norm_w && M > 4 && K == e->c.hidden && g_skinny_mode && !a.W8) {
+    if (norm_w && M > 4 && K == e->c.hidden && g_skinny_mode) {
         // 5..16 rows: staging the normalised rows in LDS (M x 8 KiB) would leave one workgroup per CU; normalise once into
         // an L2-resident scratch instead and let the MFMA weight stream take its B fragments from there
         { ProfScope ps(e, K_NORM, s); int r = vz_launch_rmsnorm(A, lda, e->d_xnorm, K, norm_w, M, K, norm_eps, s); if (r) return r; }

@@ -399,5 +399,6 @@ int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
 int vz_launch_linear(const LinearArgs& a, hipStream_t s) {
     if (g_skinny_mode && vz_skinny_ok(a)) return vz_launch_skinny(a, s);      // 2..16 rows (batched decode): one MFMA per KiB of weights
     if (vz_gemv_ok(a)) return vz_launch_gemv(a, s);
+    VZ_CHECK_ARG(!a.W8, "linear: e4m3 weights are streamed by the M <= 16 kernels only (M=%d K=%d)", a.M, a.K);
     return vz_launch_gemm(a, s);
 }

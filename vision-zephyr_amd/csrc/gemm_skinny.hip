@@ -16,6 +16,8 @@
 //     workgroup in LDS (one wave per row, row stride K + 8 elements: conflict-free fragment reads); without it (O-proj,
 //     down-proj) the B fragments are loaded straight from global memory - x is at most 16 x 14336 bf16 = 448 KiB, L2
 //     resident, and rides in the same prefetch ring as the weights.
+//   * FP8 weights (W8A16, vz_hip/quant.py): a lane's 16 bytes are the same 16 k of the step; they are widened to the two bf16
+//     fragments in registers (exact) and the row's power-of-two scale multiplies the fp32 result once.
 #include "vz_common.h"
 
 namespace {
@@ -32,6 +34,7 @@ template <bool SWIGLU, bool NORM> struct Depth { static constexpr int U = (SWIGL
 struct SkinnyParams {
     const bf16_t* A; const bf16_t* W; void* C;
     const float* bias; const bf16_t* residual; const float* norm_w;
+    const unsigned char* W8; const float* wscale;     // FP8 instantiation: e4m3 rows [N][ldw bytes] + fp32 2^e per row (vz_hip/quant.py)
     int M, N, K, lda, ldw, ldc, ldr;
     int act, out_fp32;
     float norm_eps;
@@ -45,7 +48,18 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <bool SWIGLU, bool NORM, int NW>
+// 16 e4m3 weights (k = 16g .. 16g+15 of one row) -> the two bf16 A fragments of a 64-k step; exact (v_cvt_scalef32_pk_bf16_fp8)
+__device__ __forceinline__ unsigned fp8x2_bf16x2(unsigned w, bool hi_half) {
+    return hi_half ? __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true))
+                   : __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+}
+__device__ __forceinline__ void widen_fp8(const u32x4 w, u32x4& lo, u32x4& hi) {
+    const unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    lo = (u32x4){fp8x2_bf16x2(w0, false), fp8x2_bf16x2(w0, true), fp8x2_bf16x2(w1, false), fp8x2_bf16x2(w1, true)};
+    hi = (u32x4){fp8x2_bf16x2(w2, false), fp8x2_bf16x2(w2, true), fp8x2_bf16x2(w3, false), fp8x2_bf16x2(w3, true)};
+}
+
+template <bool SWIGLU, bool NORM, int NW, bool FP8 = false>
 __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,6 +76,8 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     else { row_a = grp * 16 + fr; row_a = row_a < p.N ? row_a : p.N - 1; }
     const bf16_t* wa = p.W + (size_t)row_a * p.ldw + g * 16;
     const bf16_t* wb = p.W + (size_t)row_b * p.ldw + g * 16;
+    const unsigned char* wa8 = p.W8 + (size_t)row_a * p.ldw + g * 16;      // FP8: 16 bytes = the same 16 k of a step
+    const unsigned char* wb8 = p.W8 + (size_t)row_b * p.ldw + g * 16;
 
     // ---- this wave's K-slice, in steps of 64 k ----
     constexpr int U = Depth<SWIGLU, NORM>::U;
@@ -78,11 +94,16 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
         for (int u = 0; u < U; ++u) {
             const int s = i0 + u;
             if (s < s1) {
-                const u32x4* pa = (const u32x4*)(wa + (size_t)s * 64);
-                qa[u][0] = pa[0]; qa[u][1] = pa[1];        // default cache policy: the two halves of a line are requested by two instructions
-                if (SWIGLU) {
-                    const u32x4* pb = (const u32x4*)(wb + (size_t)s * 64);
-                    qb[u][0] = pb[0]; qb[u][1] = pb[1];
+                if (FP8) {
+                    qa[u][0] = *(const u32x4*)(wa8 + (size_t)s * 64);
+                    if (SWIGLU) qb[u][0] = *(const u32x4*)(wb8 + (size_t)s * 64);
+                } else {
+                    const u32x4* pa = (const u32x4*)(wa + (size_t)s * 64);
+                    qa[u][0] = pa[0]; qa[u][1] = pa[1];        // default cache policy: the two halves of a line are requested by two instructions
+                    if (SWIGLU) {
+                        const u32x4* pb = (const u32x4*)(wb + (size_t)s * 64);
+                        qb[u][0] = pb[0]; qb[u][1] = pb[1];
+                    }
                 }
                 if (!NORM) {
                     const u32x4* px = (const u32x4*)(xg + (size_t)s * 64);
@@ -135,11 +156,16 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
                 } else {
                     x0 = qx[u][0]; x1 = qx[u][1];
                 }
-                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qa[u][0]), as_bf16x8(x0), acc_a, 0, 0, 0);
-                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qa[u][1]), as_bf16x8(x1), acc_a, 0, 0, 0);
+                u32x4 a0 = qa[u][0], a1 = qa[u][1], b0 = qb[u][0], b1 = qb[u][1];
+                if (FP8) {
+                    widen_fp8(qa[u][0], a0, a1);
+                    if (SWIGLU) widen_fp8(qb[u][0], b0, b1);
+                }
+                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a0), as_bf16x8(x0), acc_a, 0, 0, 0);
+                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a1), as_bf16x8(x1), acc_a, 0, 0, 0);
                 if (SWIGLU) {
-                    acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qb[u][0]), as_bf16x8(x0), acc_b, 0, 0, 0);
-                    acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qb[u][1]), as_bf16x8(x1), acc_b, 0, 0, 0);
+                    acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b0), as_bf16x8(x0), acc_b, 0, 0, 0);
+                    acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b1), as_bf16x8(x1), acc_b, 0, 0, 0);
                 }
             }
         }
@@ -165,9 +191,12 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
         if (n >= n_out_total) break;
         float t;
         if (SWIGLU) {
-            t = act_silu(sa[j]) * sb[j];
+            float gt = sa[j], up = sb[j];
+            if (FP8) { gt *= p.wscale[grp * 32 + g * 4 + j]; up *= p.wscale[grp * 32 + 16 + g * 4 + j]; }    // the rows' 2^e, once
+            t = act_silu(gt) * up;
         } else {
             t = sa[j];
+            if (FP8) t *= p.wscale[n];
             if (p.bias) t += p.bias[n];
             t = apply_act(t, p.act);
         }
@@ -181,22 +210,23 @@ size_t skinny_lds(const LinearArgs& a) {
     return (a.norm_w ? (size_t)a.M * (a.K + 8) * 2 : 0) + (size_t)8 * 2 * 64 * 4 * sizeof(float);
 }
 
-template <bool SWIGLU, bool NORM, int NW>
+template <bool SWIGLU, bool NORM, int NW, bool FP8>
 int launch_nw(const SkinnyParams& p, int blocks, size_t lds, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_kernel<SWIGLU, NORM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_kernel<SWIGLU, NORM, NW, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    vz_launch_timed(skinny_kernel<SWIGLU, NORM, NW>, dim3(blocks), dim3(NW * 64), lds, s, p);
+    vz_launch_timed(skinny_kernel<SWIGLU, NORM, NW, FP8>, dim3(blocks), dim3(NW * 64), lds, s, p);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
 
 template <bool SWIGLU, bool NORM>
 int launch(const SkinnyParams& p, int blocks, size_t lds, hipStream_t s) {
-    if (blocks >= 512 && (p.K >> 6) >= 16) return launch_nw<SWIGLU, NORM, 4>(p, blocks, lds, s);
-    return launch_nw<SWIGLU, NORM, 8>(p, blocks, lds, s);
+    const bool four = blocks >= 512 && (p.K >> 6) >= 16;
+    if (p.W8) return four ? launch_nw<SWIGLU, NORM, 4, true>(p, blocks, lds, s) : launch_nw<SWIGLU, NORM, 8, true>(p, blocks, lds, s);
+    return four ? launch_nw<SWIGLU, NORM, 4, false>(p, blocks, lds, s) : launch_nw<SWIGLU, NORM, 8, false>(p, blocks, lds, s);
 }
 
 }  // namespace
@@ -204,7 +234,8 @@ int launch(const SkinnyParams& p, int blocks, size_t lds, hipStream_t s) {
 int g_skinny_mode = 1;   // vz_tune_set(9, v): 1 = 2..16-row linears use the MFMA weight stream (default), 0 = GEMV / tile GEMM as before
 
 bool vz_skinny_ok(const LinearArgs& a) {
-    if (a.M < 2 || a.M > 16 || a.W8 || (a.K & 63) != 0 || a.K < 512) return false;
+    if (a.M < 2 || a.M > 16 || (a.K & 63) != 0 || a.K < 512) return false;
+    if (a.W8 && (!a.wscale || (a.ldw & 15) != 0 || ((uintptr_t)a.W8 & 15) != 0)) return false;
     if (a.act == VZ_ACT_SWIGLU && (a.N % 32) != 0) return false;
     if ((a.lda & 7) != 0 || (a.ldw & 7) != 0) return false;                       // 16-byte fragment loads
     return skinny_lds(a) <= 160 * 1024;
@@ -214,7 +245,9 @@ int vz_init_skinny_kernels() {
     static bool done = false;
     if (done) return VZ_OK;
     // every variant a captured decode step can reach gets its dynamic-LDS limit now (never inside a stream capture)
-#define VZ_SK_ATTR(SW, NM, W) VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_kernel<SW, NM, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define VZ_SK_ATTR(SW, NM, W)                                                                                                                   \
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_kernel<SW, NM, W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_kernel<SW, NM, W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     VZ_SK_ATTR(false, false, 4) VZ_SK_ATTR(false, false, 8) VZ_SK_ATTR(false, true, 4) VZ_SK_ATTR(false, true, 8)
     VZ_SK_ATTR(true, false, 4) VZ_SK_ATTR(true, false, 8) VZ_SK_ATTR(true, true, 4) VZ_SK_ATTR(true, true, 8)
 #undef VZ_SK_ATTR
@@ -229,6 +262,7 @@ int vz_launch_skinny(const LinearArgs& a, hipStream_t s) {
     { int r = vz_init_skinny_kernels(); if (r) return r; }
     SkinnyParams p;
     p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.residual = a.residual; p.norm_w = a.norm_w;
+    p.W8 = a.W8; p.wscale = a.wscale;
     p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr;
     p.act = a.act; p.out_fp32 = a.out_fp32; p.norm_eps = a.norm_eps;
     const bool sw = a.act == VZ_ACT_SWIGLU;
