@@ -132,10 +132,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # rehearsal on a one-GPU box: VZ_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and uses gloo for the control-plane
+    # collectives (barrier, max of the timings) - the multi-rank control flow runs, the GPUs are not what is measured
+    single_dev = os.environ.get("VZ_BENCH_SINGLE_DEVICE", "0") == "1"
+    if single_dev:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if single_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
 
@@ -178,7 +186,7 @@ def main():
         decs.append(b)
     barrier()
     elapsed = time.perf_counter() - t_start
-    stats = torch.tensor([elapsed, sum(ttfts), sum(decs)], dtype=torch.float64, device=device)
+    stats = torch.tensor([elapsed, sum(ttfts), sum(decs)], dtype=torch.float64, device="cpu" if single_dev else device)
     if dist is not None:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     elapsed, ttft_sum, dec_sum = stats.tolist()
@@ -271,10 +279,14 @@ def main():
         env["VZ_BENCH_PARALLELISM"] = "tp"
         env["VZ_BENCH_TP_LEG"] = "0"
         env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 23)
+        # under torch.distributed.run the workers are CLIENTS of the agent's store (TORCHELASTIC_USE_AGENT_STORE=True); the child
+        # group lives on its own port, so its rank 0 must host the store itself - otherwise every child waits for a server forever
+        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+            env.pop(k)
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(min(args.steps, 2)), "--warmup", "1",
                "--layers", str(args.layers), "--new-tokens", str(args.new_tokens), "--no-cpu-baseline"]
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
             if rank == 0:
                 lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 if r.returncode == 0 and lines:
@@ -285,7 +297,7 @@ def main():
                     tp_leg = {"value": None, "error": f"child rc={r.returncode}: {(r.stderr or '')[-400:]}"}
         except subprocess.TimeoutExpired:
             if rank == 0:
-                tp_leg = {"value": None, "error": "tensor-parallel child timed out after 240 s"}
+                tp_leg = {"value": None, "error": "tensor-parallel child timed out after 200 s"}
         barrier()
     if rank != 0:
         if dist is not None:
