@@ -11,15 +11,18 @@ from util import check_close
 pytestmark = pytest.mark.gpu
 
 
-def test_tp2_shards_reproduce_single_gpu_prefill():
+@pytest.mark.parametrize("world", [2, 8])
+def test_tp_shards_reproduce_single_gpu_prefill(world):
+    """world = 8 is the driver's node: 4 query + 1 KV head, 1792 MLP columns (not a multiple of 512: the one-row down-proj of a
+    decode step leaves the GEMV for the tile GEMM there) and 126 vocab rows per rank."""
     from vz_hip import binding as B, synth
     from vz_hip.engine import Engine, rope_tables
     cfg = synth.ArchConfig(n_layers=1, vocab=1001, clip_layers=20)      # odd vocab: ragged vocab shards
     full = Engine(cfg, max_ctx=128, max_tiles=1, max_text=8)
     full.load_synthetic(0)
     shards = []
-    for r in range(2):
-        e = Engine(cfg, max_ctx=128, max_tiles=1, max_text=8, tp_size=2, tp_rank=r)
+    for r in range(world):
+        e = Engine(cfg, max_ctx=128, max_tiles=1, max_text=8, tp_size=world, tp_rank=r)
         shards.append(e)
     # register only the LLM shards (finalize() would also want CLIP / Q-Former, which are replicated and not needed here)
     for e in shards:
@@ -31,13 +34,14 @@ def test_tp2_shards_reproduce_single_gpu_prefill():
     ref, _ = full.prefill(x.unsqueeze(0), [S], all_logits=True, last_logits=False)
     cos, sin = (t.cuda() for t in rope_tables(cfg, 128))
     pos = torch.arange(S, dtype=torch.int32, device="cuda")
-    Hq, Hkv = cfg.n_heads // 2, cfg.n_kv_heads // 2
+    Hq, Hkv = cfg.n_heads // world, cfg.n_kv_heads // world
+    vp = (cfg.vocab + world - 1) // world
 
     def allreduce(parts):
         return sum(p.float() for p in parts).bfloat16()
 
     xs = x
-    parts_o, parts_d, atts = [], [], []
+    parts_o, parts_d = [], []
     for r, e in enumerate(shards):
         w = e.w
         y = B.rmsnorm(xs, w["llm.0.in_norm"], cfg.rms_eps)
@@ -53,18 +57,22 @@ def test_tp2_shards_reproduce_single_gpu_prefill():
         w = e.w
         y = B.rmsnorm(xs, w["llm.0.post_norm"], cfg.rms_eps)
         act = B.linear(y, w["llm.0.gu.w"], act=B.ACT_SWIGLU)
-        assert act.shape[1] == cfg.inter // 2
+        assert act.shape[1] == cfg.inter // world
         parts_d.append(B.linear(act, w["llm.0.down.w"], residual=xs if r == 0 else None))
+        # the decode step's one-row forms of the same shard (weight-stream kernels where the shapes allow, tile GEMM otherwise)
+        one = B.linear(act[:1].contiguous(), w["llm.0.down.w"])
+        check_close(f"tp{world} rank {r} one-row down-proj", one, parts_d[-1][:1].float() - (xs[:1].float() if r == 0 else 0), 3e-2, 8e-3)
     xs = allreduce(parts_d)
     logits = []
     for r, e in enumerate(shards):
         w = e.w
         h = B.rmsnorm(xs, w["llm.norm"], cfg.rms_eps)
-        assert w["llm.lm_head"].shape[0] == 501
+        assert w["llm.lm_head"].shape[0] == vp
         logits.append(B.linear(h, w["llm.lm_head"], out_fp32=True))
     got = torch.cat(logits, dim=1)[:, :cfg.vocab]
-    assert float(logits[1][:, 500:].abs().max()) == 0.0          # the padded vocab row of the last shard is inert
-    check_close("tp2 shards vs tp1 engine logits", got, ref[0], 2e-2, 6e-3)
+    n_last = cfg.vocab - (world - 1) * vp
+    assert float(logits[-1][:, n_last:].abs().max()) == 0.0      # the padded vocab rows of the last shard are inert
+    check_close(f"tp{world} shards vs tp1 engine logits", got, ref[0], 2e-2, 6e-3)
     for e in shards + [full]:
         e.close()
 
@@ -161,3 +169,40 @@ def test_rccl_call_sites_on_one_rank():
     assert torch.equal(logits, ref_logits)
     assert torch.equal(new_ids, ref_ids)
     assert gathered.shape == (1, 3, cfg.hidden) and torch.equal(gathered[0], x[0, :3])
+
+
+@pytest.mark.parametrize("world,rank", [(8, 5), (4, 0), (2, 1)])
+def test_one_rank_of_a_tp_engine_runs_its_local_path(world, rank):
+    """Shape rehearsal on one GPU: ONE rank of a tp_size = 2 / 4 / 8 engine with the full model loaded (its Zephyr shards, CLIP /
+    Q-Former replicated) runs image -> first token -> a few decode steps with the collectives skipped (vz_tune_set(7, 2)).
+    Logits are meaningless without the other ranks' partial sums; what is checked is that every local kernel accepts the
+    shard shapes (1792 MLP columns and one KV head at tp 8, tile-DP deal of 5 tiles, vocab shard + repack) and stays finite."""
+    from vz_hip import binding as B, synth
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    cfg = synth.ArchConfig(n_layers=2)
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.n_layers,
+                         num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab,
+                         rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, sliding_window=cfg.sliding_window,
+                         eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    hf.mm_hidden_size = 5120
+    try:
+        B.check(B.lib().vz_tune_set(7, 2))
+        model = VisZephyrForCausalLM(hf, device="cuda:0", max_batch=2, max_ctx=512, max_tiles=5, max_text=64, tp_size=world, tp_rank=rank)
+        model.engine.load_synthetic(0)                       # no init_comm: the collectives are skipped in this rehearsal
+        model.get_vision_tower().is_loaded = True
+        eng = model.engine
+        assert eng.w["llm.0.gu.w"].shape[0] == 2 * cfg.inter // world and eng.w["llm.0.qkv.w"].shape[0] == (cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim // world
+        tiles = synth.synth_tiles(5, seed=1).to(model.device).bfloat16()
+        ids = synth.synth_ids(40, cfg.vocab, image_pos=5, seed=2).unsqueeze(0).to(model.device)
+        out = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=5, eos_token_id=None, pad_token_id=2)
+        assert out.shape == (1, 5) and int(out.min()) >= 0 and int(out.max()) < cfg.vocab
+        logits = model(input_ids=ids, images=[tiles]).logits
+        assert logits.shape == (1, 39 + 32 * 5, cfg.vocab) and bool(torch.isfinite(logits).all())
+        # two text rows through the batched decode path of the shard
+        ids2 = torch.stack([synth.synth_ids(12, cfg.vocab, image_pos=-1, seed=3 + b) for b in range(2)]).to(model.device)
+        out2 = model.generate(input_ids=ids2, do_sample=False, max_new_tokens=4, eos_token_id=None, pad_token_id=2)
+        assert out2.shape == (2, 4)
+    finally:
+        B.check(B.lib().vz_tune_set(7, 0))

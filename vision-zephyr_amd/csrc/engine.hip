@@ -292,8 +292,10 @@ extern "C" int vz_engine_create(const vz_config* cfg, vz_engine** out) {
     VZ_CHECK_ARG(c.clip_layers + 1 >= c.fusion_groups * c.fusion_layers_per_group + 1, "engine_create: CLIP too shallow for the fusion");
     VZ_CHECK_ARG(c.max_batch >= 1 && c.max_ctx >= 64 && c.max_tiles >= 1 && c.max_text >= 0, "engine_create: bad capacity");
     VZ_CHECK_ARG(c.tp_size >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_size, "engine_create: bad tp_size/tp_rank %d/%d", c.tp_size, c.tp_rank);
-    VZ_CHECK_ARG(c.n_kv_heads % c.tp_size == 0 && c.n_heads % c.tp_size == 0 && (c.inter / c.tp_size) % 512 == 0 && c.inter % c.tp_size == 0,
-                 "engine_create: tp_size %d must divide the KV heads (%d) and leave MLP shards that are multiples of 512", c.tp_size, c.n_kv_heads);
+    // MLP shard: 16-row gate|up interleave and K %% 64 of the down-proj GEMM (tp 8: 14336 / 8 = 1792 columns; a shard that is not a
+    // multiple of 512 takes the tile-GEMM path for the one-row down-proj instead of the GEMV)
+    VZ_CHECK_ARG(c.n_kv_heads % c.tp_size == 0 && c.n_heads % c.tp_size == 0 && (c.inter / c.tp_size) % 64 == 0 && c.inter % c.tp_size == 0,
+                 "engine_create: tp_size %d must divide the KV heads (%d) and leave MLP shards that are multiples of 64", c.tp_size, c.n_kv_heads);
     VZ_CHECK_ARG((c.n_heads / c.tp_size) == 4 * (c.n_kv_heads / c.tp_size), "engine_create: 4 query heads per KV head expected");
     { int r = vz_init_gemm_kernels(); if (r) return r; r = vz_init_attention_kernels(); if (r) return r; }
     vz_engine* e = new vz_engine();
@@ -614,8 +616,13 @@ extern "C" int vz_embed_splice(vz_engine* e, const int* d_kind, const int* d_idx
 static int g_force_comm = 0;
 static inline bool tp_local(const vz_engine* e) { return e->tp == 1 && !(g_force_comm && e->comm); }
 
+// vz_tune_set(7, 2): shape rehearsal of ONE rank of a tp_size > 1 engine on a single GPU - every collective is skipped (the
+// partial sums / vocab shard are left as they are), so all local kernels run with that rank's shard shapes; results are
+// meaningless as logits, the point is that nothing on the local path rejects the shapes of tp 2 / 4 / 8.
+static inline bool tp_skip(const vz_engine* e) { return e->tp > 1 && g_force_comm == 2; }
+
 static int tp_allreduce_bf16(vz_engine* e, bf16_t* buf, size_t count, hipStream_t s) {
-    if (tp_local(e)) return VZ_OK;
+    if (tp_local(e) || tp_skip(e)) return VZ_OK;
     if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
     ProfScope ps(e, K_OTHER, s);
     ncclResult_t r = ncclAllReduce(buf, buf, count, ncclBfloat16, ncclSum, e->comm, s);
@@ -644,7 +651,12 @@ static int lm_head_logits(vz_engine* e, const bf16_t* h, int rows, float* out, h
     }
     float* local = e->d_gather + local_off;
     RC(linear(e, 0, h, H, lm, H, local, e->Vp, rows, e->Vp, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps, lm8, lms));
-    if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
+    if (!e->comm && !tp_skip(e)) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
+    if (tp_skip(e)) {     // rehearsal: this rank's shard goes to its own chunk, the others stay zero
+        VZ_CHECK_HIP(hipMemsetAsync(e->d_gather, 0, (size_t)e->tp * rows * e->Vp * sizeof(float), s));
+        VZ_CHECK_HIP(hipMemcpyAsync(e->d_gather + (size_t)e->rank * rows * e->Vp, local, (size_t)rows * e->Vp * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return vz_launch_repack_logits(e->d_gather, out, rows, e->Vp, c.vocab, e->tp, s);
+    }
     ncclResult_t r = ncclAllGather(local, e->d_gather, (size_t)rows * e->Vp, ncclFloat, e->comm, s);
     if (r != ncclSuccess) { vz_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
     return vz_launch_repack_logits(e->d_gather, out, rows, e->Vp, c.vocab, e->tp, s);
@@ -674,6 +686,11 @@ extern "C" int vz_tp_all_gather(vz_engine* e, const void* d_send, void* d_recv, 
     VZ_CHECK_ARG(e && d_send && d_recv && bytes_per_rank > 0, "tp_all_gather: bad argument");
     hipStream_t s = (hipStream_t)stream;
     if (tp_local(e)) { VZ_CHECK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, s)); return VZ_OK; }
+    if (tp_skip(e)) {     // rehearsal: own chunk only
+        VZ_CHECK_HIP(hipMemsetAsync(d_recv, 0, bytes_per_rank * e->tp, s));
+        VZ_CHECK_HIP(hipMemcpyAsync((char*)d_recv + bytes_per_rank * e->rank, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, s));
+        return VZ_OK;
+    }
     if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
     ProfScope ps(e, K_OTHER, s);
     ncclResult_t r = ncclAllGather(d_send, d_recv, bytes_per_rank, ncclInt8, e->comm, s);
