@@ -516,3 +516,43 @@ def test_wide_batch_decode_matches_prefill(env, Bn):
     assert same >= 2
     del model
     torch.cuda.empty_cache()
+
+
+def test_sliding_window_and_context_capacity(env):
+    """Mistral's sliding window (hf:models/mistral/modeling_mistral.py:364-371; Zephyr: 4096) at engine level with a small window:
+    prefill of 100 tokens and teacher-forced decode steps against the oracle's windowed mask, then the capacity edge:
+    prompt + new tokens == max_ctx runs, one more raises."""
+    import dataclasses
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    O, sd, synth = env["O"], env["sd"], env["synth"]
+    cfg = dataclasses.replace(env["cfg"], sliding_window=48)
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.n_layers,
+                         num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab,
+                         rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, sliding_window=48,
+                         eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    hf.mm_hidden_size = 5120
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=112, max_tiles=1, max_text=16)
+    eng = model.engine
+    S = 100
+    ids = synth.synth_ids(S + 4, cfg.vocab, image_pos=-1, seed=31)
+    o16, _ = O.llm_forward(cfg, sd, O.embed_tokens(sd, ids.unsqueeze(0), O.BF16), P=O.BF16)
+    o32, _ = O.llm_forward(cfg, sd, O.embed_tokens(sd, ids.unsqueeze(0), O.FP32), P=O.FP32)
+    # the window matters: the same tokens under the full causal mask give visibly different logits late in the sequence
+    full32, _ = O.llm_forward(env["cfg"], sd, O.embed_tokens(sd, ids.unsqueeze(0), O.FP32), P=O.FP32)
+    assert errs(o32[0, 90], full32[0, 90])[1] > 0.05
+    emb = eng.embed_tokens(ids).unsqueeze(0)
+    got, _ = eng.prefill(emb[:, :S].contiguous(), [S], all_logits=True, last_logits=False)
+    band("windowed prefill logits", got, o16[:, :S], o32[:, :S])
+    for t in range(3):                                              # decode steps S, S+1, S+2 look back 48 positions only
+        eng.decode_begin(ids[S + t:S + t + 1].to(torch.int32), [S + t], [S + t])
+        _, lg = eng.decode_steps(1, return_logits=True)
+        band(f"windowed decode step {t}", lg[0, 0], o16[0, S + t], o32[0, S + t])
+    # capacity: 100 + 12 == max_ctx is served, 100 + 13 is refused before anything is launched
+    out = model.generate(input_ids=ids[:S].unsqueeze(0), do_sample=False, max_new_tokens=12, eos_token_id=None)
+    assert out.shape == (1, 12)
+    with pytest.raises(ValueError):
+        model.generate(input_ids=ids[:S].unsqueeze(0), do_sample=False, max_new_tokens=13, eos_token_id=None)
+    del model
+    torch.cuda.empty_cache()
