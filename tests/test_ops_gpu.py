@@ -191,6 +191,10 @@ ATTN_CASES = [
     # name, B, Sq, Sk, Hq, Hkv, D, causal, q_pos0, window, ragged kv_len
     ("clip", 2, 577, 577, 16, 16, 64, False, 0, 0, False),
     ("zephyr prefill", 1, 300, 300, 32, 8, 128, True, 0, 4096, False),
+    # 12 query blocks x 32 heads = 384 workgroups, 256 is not a multiple of 12: the causal load-balancing order must stay a
+    # bijection of the query blocks within every (head, batch) row (it was not; S = 2048 hid it)
+    ("zephyr prefill 1501", 1, 1501, 1501, 32, 8, 128, True, 0, 4096, False),
+    ("zephyr prefill batch 2 x 700", 2, 700, 700, 32, 8, 128, True, 0, 4096, False),
     ("zephyr padded batch", 2, 200, 200, 8, 2, 128, True, 0, 4096, True),
     ("zephyr window", 1, 260, 260, 4, 1, 128, True, 0, 100, False),
     ("qformer self blk0", 2, 32, 63, 8, 8, 512, False, 0, 0, False),

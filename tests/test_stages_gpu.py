@@ -556,3 +556,62 @@ def test_sliding_window_and_context_capacity(env):
         model.generate(input_ids=ids[:S].unsqueeze(0), do_sample=False, max_new_tokens=13, eos_token_id=None)
     del model
     torch.cuda.empty_cache()
+
+
+def test_full_size_request_properties(env):
+    """BASELINE.json configs[2] at full size (5 anyres tiles + 1889 ids -> S = 2048; 2 decoder layers keep it quick), checked
+    through size-independent properties instead of the CPU oracle (which needs minutes there):
+      * tiles are independent units: encoding a permuted tile list permutes the visual tokens (bit for bit with whole-tile GEMMs);
+      * generate's last-row logits path and forward's all-position path agree on the first token;
+      * teacher forcing at context 2048: the decode step's logits equal the prefill logits of the 2049-token sequence;
+      * the captured decode graph and the eager step produce the same ids."""
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    cfg, synth = env["cfg"], env["synth"]
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.n_layers,
+                         num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab,
+                         rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, sliding_window=cfg.sliding_window,
+                         eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    hf.mm_hidden_size = 5120
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=2048 + 64, max_tiles=5, max_text=2048)
+    eng = model.engine
+    tiles = synth.synth_tiles(5, seed=1).to(model.device).bfloat16()
+    ids = synth.synth_ids(1889, cfg.vocab, image_pos=5, seed=2).unsqueeze(0).to(model.device)
+    # tile independence
+    perm = torch.tensor([3, 0, 4, 1, 2], device=model.device)
+    text = eng.embed_tokens(ids[0][ids[0] != -200]).unsqueeze(0)
+    from vz_hip import binding as B
+    a = model.encode_images(tiles, text, tile_sample=[0] * 5)
+    b = model.encode_images(tiles[perm], text, tile_sample=[0] * 5)
+    assert a.shape == (5, 32, cfg.hidden)
+    # production dispatch: the stream-K tail of the 256x256 GEMM sums K in slices for the rows that fall into the split tiles
+    # (fp32 re-association), so a moved tile agrees to bf16 rounding through the 8 Q-Former blocks ...
+    check_close("permuted tiles (production dispatch)", b, a[perm].float(), 0.25, 2e-2)
+    try:                                                              # ... and bit for bit with whole tiles only
+        B.check(B.lib().vz_tune_set(4, 0))
+        a0 = model.encode_images(tiles, text, tile_sample=[0] * 5)
+        b0 = model.encode_images(tiles[perm], text, tile_sample=[0] * 5)
+    finally:
+        B.check(B.lib().vz_tune_set(4, 1))
+    assert torch.equal(b0, a0[perm])
+    # forward (all positions) vs generate (last row)
+    logits = model(input_ids=ids, images=[tiles]).logits
+    assert logits.shape == (1, 2048, cfg.vocab)
+    out = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=9, eos_token_id=None)
+    assert out.shape == (1, 9) and int(out[0, 0]) == int(logits[0, -1].argmax())
+    # teacher forcing at full context: prefill of S+1 embeddings vs prefill of S + one decode step
+    emb = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles])[4]
+    nxt = out[0, :1].to(torch.int32)
+    emb1 = torch.cat([emb, eng.embed_tokens(nxt.to(torch.long)).view(1, 1, -1)], dim=1)
+    full, _ = eng.prefill(emb1, [2049], all_logits=True, last_logits=False)
+    eng.prefill(emb, [2048], all_logits=False, last_logits=True)
+    eng.decode_begin(nxt, [2048], [2048])
+    ids_e, lg = eng.decode_steps(4, return_logits=True)              # debug logits: eager steps
+    check_close("decode step at ctx 2048 vs prefill of 2049", lg[0, 0], full[0, 2048], 3e-2, 1e-2)
+    eng.prefill(emb, [2048], all_logits=False, last_logits=True)
+    eng.decode_begin(nxt, [2048], [2048])
+    ids_g = eng.decode_steps(4)                                       # captured graph
+    assert torch.equal(ids_g, ids_e) and ids_g[0].tolist() == out[0, 1:5].tolist()
+    del model
+    torch.cuda.empty_cache()

@@ -276,11 +276,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
-    // Causal work grows with the query block index.  Workgroups n and n + 256 tend to share a CU, and 256 is a multiple
-    // of the block count per head, so every other residency round walks the query blocks backwards: a CU then pairs a
-    // long block with a short one (speed only; any placement computes the same values).
+    // Causal work grows with the query block index.  Workgroups n and n + 256 tend to share a CU, so every other residency
+    // round (256 workgroups = 256 / blocks-per-row rows) walks the query blocks backwards: a CU then pairs a long block with
+    // a short one (speed only; any placement computes the same values).
+    // The direction is a function of the (head, batch) ROW alone - every row is a bijection of its query blocks whatever the
+    // block count (a parity taken from the linear workgroup id flipped in the middle of a row whenever 256 was not a multiple
+    // of the blocks per row: some query blocks were computed twice and others never, for every prompt length that is not
+    // a multiple of 2048 - found by tests/test_stages_gpu.py::test_full_size_request_properties).
     int qb = blockIdx.x;
-    if (p.causal && (((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8) & 1)) qb = gridDim.x - 1 - qb;
+    {
+        const int row = blockIdx.y + gridDim.y * blockIdx.z;
+        const int rows_per_round = gridDim.x >= 256 ? 1 : 256 / gridDim.x;
+        if (p.causal && ((row / rows_per_round) & 1)) qb = gridDim.x - 1 - qb;
+    }
     const int q0 = qb * 128;
     const int hk = h / (p.Hq / p.Hkv);
     const int kv_len = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
