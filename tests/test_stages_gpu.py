@@ -595,6 +595,12 @@ def test_full_size_request_properties(env):
     finally:
         B.check(B.lib().vz_tune_set(4, 1))
     assert torch.equal(b0, a0[perm])
+    # the Q-Former at the full text length (block 0 attends over 32 + 1888 rows) for one tile, against the oracle's band
+    O, sd = env["O"], env["sd"]
+    feats1 = O.clip_tower(cfg, sd, synth.synth_tiles(5, seed=1)[:1], O.BF16)
+    te = O.embed_tokens(sd, ids[0][ids[0] != -200].cpu(), O.BF16).unsqueeze(0)
+    qf_hip = eng.qformer(feats1.bfloat16(), te.bfloat16(), [0])
+    band("qformer at L=1888", qf_hip, O.qformer(cfg, sd, feats1, te, O.BF16), O.qformer(cfg, sd, feats1, te, O.FP32))
     # forward (all positions) vs generate (last row)
     logits = model(input_ids=ids, images=[tiles]).logits
     assert logits.shape == (1, 2048, cfg.vocab)
@@ -615,3 +621,23 @@ def test_full_size_request_properties(env):
     assert torch.equal(ids_g, ids_e) and ids_g[0].tolist() == out[0, 1:5].tolist()
     del model
     torch.cuda.empty_cache()
+
+
+def test_medium_prompt_batch_against_oracle(env):
+    """several query blocks per head and both tile GEMMs in play (the S = 127 cases above fit one attention block and one GEMM
+    row tile): a ragged batch of 2 text prompts, 450 and 333 tokens, prefill logits of every valid position in the oracle's band."""
+    O, cfg, sd = env["O"], env["cfg"], env["sd"]
+    eng = env["model"].engine
+    lens = [450, 333]                      # env engine: max_ctx 512
+    Smax = max(lens)
+    ids = torch.full((2, Smax), 2, dtype=torch.long)
+    for b, n in enumerate(lens):
+        ids[b, :n] = env["synth"].synth_ids(n, cfg.vocab, image_pos=-1, seed=50 + b)
+    emb = eng.embed_tokens(ids)
+    full, _ = eng.prefill(emb, lens, all_logits=True, last_logits=False)
+    for b, n in enumerate(lens):
+        x16 = O.embed_tokens(sd, ids[b:b + 1, :n], O.BF16)
+        x32 = O.embed_tokens(sd, ids[b:b + 1, :n], O.FP32)
+        o16, _ = O.llm_forward(cfg, sd, x16, P=O.BF16)
+        o32, _ = O.llm_forward(cfg, sd, x32, P=O.FP32)
+        band(f"medium prompt row {b} ({n} tokens)", full[b, :n], o16[0], o32[0])
