@@ -212,7 +212,7 @@ def test_attention(B, case):
     v = _rand((Bn, Sk, Hkv, D), 1.0, 32).bfloat16()
     kv_len = None
     if ragged:
-        kv_len = torch.tensor([Sk, Sk // 2 + 3][:Bn], dtype=torch.int32, device="cuda")
+        kv_len = torch.tensor([Sk, min(Sk, Sk // 2 + 3), Sk // 3 + 1][:Bn], dtype=torch.int32, device="cuda")
     scale = D ** -0.5
     out = B.attention(q, k, v, scale, causal, q_pos0, window, kv_len)
     ref = _ref_attention(q, k, v, scale, causal, q_pos0, window, kv_len)
@@ -549,3 +549,66 @@ def test_skinny_gemm_fused_rmsnorm(B, M, act):
         finally:
             B.check(B.lib().vz_tune_set(9, 1))
         check_close(f"gemv vs skinny fused norm M{M}", gv, out, 1e-4, 1e-4)
+
+
+# ---- seeded shape fuzz through the PRODUCTION dispatch: every kernel family must agree with the fp64 reference at shapes
+# ---- nobody tuned for (ragged M / N, odd tile counts, grids that do not divide the CU count, every epilogue) ----
+def _fuzz_linear_cases(n=28, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))      # noqa: E731
+    cases = []
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:
+            M = ri(1, 16)                                   # weight-stream kernels
+            K = 512 * ri(1, 12)
+        elif kind == 1:
+            M = ri(17, 600)                                 # small tile grids, split-K
+            K = 64 * ri(1, 96)
+        else:
+            M = ri(600, 3100)                               # 128^2 / 256^2 tile GEMMs, stream-K tails
+            K = 64 * ri(4, 80)
+        act = ri(0, 3)
+        N = (32 * ri(1, 280)) if act == 3 else ri(16, 9000)
+        if act == 3 and M <= 8:
+            N = 64 * ri(1, 140)
+        cases.append((M, N, K, act, bool(ri(0, 1)), bool(ri(0, 1)), bool(ri(0, 3) == 0)))
+    return cases
+
+
+@pytest.mark.parametrize("M,N,K,act,use_bias,use_res,fp32", _fuzz_linear_cases())
+def test_linear_dispatch_shape_fuzz(B, M, N, K, act, use_bias, use_res, fp32):
+    x = _rand((M, K), 1.0, M + N).bfloat16()
+    w = _rand((N, K), 0.04, N + K).bfloat16()
+    n_out = N // 2 if act == 3 else N
+    bias = _rand((N,), 0.3, 7) if (use_bias and act != 3) else None
+    res = _rand((M, n_out), 1.0, 8).bfloat16() if use_res else None
+    out = B.linear(x, w, bias=bias, residual=res, act=act, out_fp32=fp32)
+    ref = _ref_linear(x, w, bias, res, act)
+    if fp32:
+        check_close(f"fuzz linear {M}x{N}x{K} act{act} fp32", out, ref, 2e-4, 1e-4)
+    else:
+        check_close(f"fuzz linear {M}x{N}x{K} act{act}", out, ref, BF16_MAX, BF16_L2)
+
+
+def _fuzz_attention_cases(n=14, seed=4321):
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))      # noqa: E731
+    cases = []
+    for i in range(n):
+        D = (64, 128)[i % 2]
+        Hkv = (1, 2, 4, 8)[ri(0, 3)]
+        Hq = Hkv * (1 if D == 64 else (1, 4)[ri(0, 1)])
+        Bn = ri(1, 3)
+        Sq = ri(1, 1700 if Bn == 1 else 600)
+        causal = D == 128 or bool(ri(0, 1))
+        q_pos0 = 0
+        Sk = Sq if causal else ri(1, 900)
+        window = (0, 4096, ri(16, 300))[ri(0, 2)] if causal else 0
+        cases.append((f"fuzz{i}", Bn, Sq, Sk, Hq, Hkv, D, causal, q_pos0, window, Bn > 1 and bool(ri(0, 1))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_attention_cases(), ids=lambda c: f"{c[0]}-B{c[1]}-Sq{c[2]}-Sk{c[3]}-H{c[4]}/{c[5]}-D{c[6]}-c{int(c[7])}-w{c[9]}")
+def test_attention_shape_fuzz(B, case):
+    test_attention(B, case)
