@@ -220,6 +220,12 @@ int vz_llm_prefill(vz_engine* e, const void* d_embeds, int B, int S, const int* 
 int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, const int* h_next_pos, const int* h_ctx_len,
                         vz_stream stream);
 int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d_logits_dbg, vz_stream stream);
+/* Continuous batching.  vz_llm_prefill_rows: vz_llm_prefill into KV-cache rows row0 .. row0+B-1;
+ * vz_llm_decode_set_row: (re)arm one row of the running decode batch - next input token, rotary position, context length -
+ * without touching the others (a finished row is parked with ctx_len 0 until a new request is prefilled into it). */
+int vz_llm_prefill_rows(vz_engine* e, int row0, const void* d_embeds, int B, int S, const int* h_seqlens, const int* d_pos,
+                        float* d_logits_all, float* d_logits_last, vz_stream stream);
+int vz_llm_decode_set_row(vz_engine* e, int row, int token, int next_pos, int ctx_len, vz_stream stream);
 
 /* ---- anyres preprocessing on the device (ref:vis_zephyr/model/multi_scale_process.py:70-171) ----
  * vz_op_resample_u8: Pillow's 8-bit LANCZOS `Image.resize` (horizontal pass, 8-bit intermediate, vertical pass) of an

@@ -706,11 +706,19 @@ static bf16_t* vc_of(vz_engine* e, int layer) { return kc_of(e, layer) + e->kv_l
 
 extern "C" int vz_llm_prefill(vz_engine* e, const void* d_embeds, int B, int S, const int* h_seqlens, const int* d_pos,
                               float* d_logits_all, float* d_logits_last, vz_stream stream) {
+    return vz_llm_prefill_rows(e, 0, d_embeds, B, S, h_seqlens, d_pos, d_logits_all, d_logits_last, stream);
+}
+
+// the same prefill into KV-cache rows row0 .. row0 + B - 1 (continuous batching: a new request enters a free row while the
+// other rows keep their context)
+extern "C" int vz_llm_prefill_rows(vz_engine* e, int row0, const void* d_embeds, int B, int S, const int* h_seqlens, const int* d_pos,
+                                   float* d_logits_all, float* d_logits_last, vz_stream stream) {
     NEED_READY();
     const vz_config& c = e->c;
     hipStream_t s = (hipStream_t)stream;
-    VZ_CHECK_ARG(d_embeds && h_seqlens && d_pos && B >= 1 && B <= c.max_batch && S >= 1 && S <= c.max_ctx,
-                 "prefill: B=%d S=%d outside capacity (max_batch %d, max_ctx %d)", B, S, c.max_batch, c.max_ctx);
+    VZ_CHECK_ARG(d_embeds && h_seqlens && d_pos && B >= 1 && row0 >= 0 && row0 + B <= c.max_batch && S >= 1 && S <= c.max_ctx,
+                 "prefill: rows %d..%d, S=%d outside capacity (max_batch %d, max_ctx %d)", row0, row0 + B - 1, S, c.max_batch, c.max_ctx);
+    const size_t row_off = (size_t)row0 * e->Hkv_l * c.max_ctx * c.head_dim;      // cache rows are [kv head][max_ctx][128] blocks
     VZ_CHECK_ARG(e->cosT && e->rope_max >= c.max_ctx, "prefill: rotary tables not set or shorter than max_ctx");
     for (int b = 0; b < B; ++b) VZ_CHECK_ARG(h_seqlens[b] >= 1 && h_seqlens[b] <= S, "prefill: seqlen[%d]=%d outside [1,%d]", b, h_seqlens[b], S);
     const int H = c.hidden, D = c.head_dim, Hq = e->Hq_l, Hkv = e->Hkv_l, QKV = (Hq + 2 * Hkv) * D, I = e->I_l, A = Hq * D;
@@ -748,11 +756,11 @@ extern "C" int vz_llm_prefill(vz_engine* e, const void* d_embeds, int B, int S, 
         const std::string p = "llm." + std::to_string(i) + ".";
         { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(x, H, y, H, WF(p + "in_norm", H), rows, H, c.rms_eps, s)); }
         RC(linear(e, 0, y, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, rows, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s));
-        { ProfScope ps(e, K_OTHER, s); RC(vz_launch_rope_kv(qkv, QKV, q, kc_of(e, i), vc_of(e, i), e->cosT, e->sinT, d_pos, d_slot, B, S, Hq, Hkv, D, c.max_ctx, s)); }
+        { ProfScope ps(e, K_OTHER, s); RC(vz_launch_rope_kv(qkv, QKV, q, kc_of(e, i) + row_off, vc_of(e, i) + row_off, e->cosT, e->sinT, d_pos, d_slot, B, S, Hq, Hkv, D, c.max_ctx, s)); }
         {
             ProfScope ps(e, K_ATTN, s);
             AttnArgs a;
-            a.q = q; a.k = kc_of(e, i); a.v = vc_of(e, i); a.o = att;
+            a.q = q; a.k = kc_of(e, i) + row_off; a.v = vc_of(e, i) + row_off; a.o = att;
             a.B = B; a.Sq = S; a.Sk = S; a.Hq = Hq; a.Hkv = Hkv; a.head_dim = D;
             a.q_bs = (long)S * A; a.q_ss = A; a.q_hs = D;
             a.k_bs = a.v_bs = (long)Hkv * c.max_ctx * D; a.k_ss = a.v_ss = D; a.k_hs = a.v_hs = (long)c.max_ctx * D;
@@ -798,7 +806,7 @@ extern "C" int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, 
     const int mb = c.max_batch;
     std::vector<int> h(3 * mb + 4, 0);
     for (int b = 0; b < B; ++b) {
-        VZ_CHECK_ARG(h_ctx_len[b] >= 1 && h_ctx_len[b] < c.max_ctx, "decode_begin: ctx_len[%d]=%d outside [1,%d)", b, h_ctx_len[b], c.max_ctx);
+        VZ_CHECK_ARG(h_ctx_len[b] >= 0 && h_ctx_len[b] < c.max_ctx, "decode_begin: ctx_len[%d]=%d outside [0,%d)", b, h_ctx_len[b], c.max_ctx);
         h[b] = h_next_pos[b];            // pos
         h[mb + b] = h_ctx_len[b];        // slot the next token is written to
         h[2 * mb + b] = h_ctx_len[b] + 1;  // keys visible to the next token
@@ -806,6 +814,24 @@ extern "C" int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, 
     RC(upload_ints(e, h.data(), h.size(), e->d_state + mb, s));   // [pos | slot | len | step=0]
     VZ_CHECK_HIP(hipMemcpyAsync(e->d_state, d_first_ids, B * sizeof(int), hipMemcpyDeviceToDevice, s));
     e->dec_B = B;
+    return VZ_OK;
+}
+
+// Continuous batching: (re)arm ONE row of a running decode batch - its next input token, rotary position and context length -
+// without touching the other rows or the step counter.  A finished row is parked the same way (any token, position 0, context
+// 0): it keeps stepping harmlessly inside its own cache row until a new request is prefilled into it (vz_llm_prefill_rows).
+extern "C" int vz_llm_decode_set_row(vz_engine* e, int row, int token, int next_pos, int ctx_len, vz_stream stream) {
+    NEED_READY();
+    const vz_config& c = e->c;
+    VZ_CHECK_ARG(e->dec_B >= 1 && row >= 0 && row < e->dec_B, "decode_set_row: row %d outside the running batch of %d", row, e->dec_B);
+    VZ_CHECK_ARG(ctx_len >= 0 && ctx_len < c.max_ctx && next_pos >= 0, "decode_set_row: ctx_len %d / pos %d outside [0,%d)", ctx_len, next_pos, c.max_ctx);
+    const int mb = c.max_batch;
+    const int h[4] = {token, next_pos, ctx_len, ctx_len + 1};     // cur | pos | slot | len
+    hipStream_t s = (hipStream_t)stream;
+    for (int k = 0; k < 4; ++k) {
+        // four 4-byte updates through the pinned staging path of upload_ints (stream-ordered, safe against a following launch)
+        RC(upload_ints(e, &h[k], 1, e->d_state + k * mb + row, s));
+    }
     return VZ_OK;
 }
 

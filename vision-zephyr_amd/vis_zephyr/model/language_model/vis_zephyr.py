@@ -324,6 +324,69 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
             cols.append(chunk)
         return torch.cat(cols, dim=1).to(self.device)
 
+    # ---- continuous batching: the 23 K-item eval loop without waiting for a batch's longest answer ----
+    @torch.no_grad()
+    def generate_stream(self, requests, max_new_tokens: int = 128, eos_token_id=None, rows: Optional[int] = None, sync_every: int = 16):
+        """Greedy generation over an iterable of requests - dicts with `input_ids` [1, L] (IMAGE_TOKEN_INDEX sentinels allowed),
+        optional `images` ([N,3,336,336]) / `images_size`, optional `max_new_tokens` - with CONTINUOUS batching: up to `rows`
+        KV-cache rows decode together; a row whose sequence ends (eos or its token budget) is re-armed with the next request at
+        the next host sync (every `sync_every` steps), the other rows keep decoding.  Yields `(index, LongTensor[n_new])` in
+        completion order; every sequence gets exactly the tokens `generate` gives it alone (rows are independent)."""
+        from vz_hip import binding as B
+        eng = self.engine
+        if eos_token_id is None:
+            eos_token_id = self.generation_config.eos_token_id
+        eos = set() if eos_token_id is None else ({int(eos_token_id)} if isinstance(eos_token_id, int) else {int(t) for t in eos_token_id})
+        n_rows = min(eng.max_batch, 16) if rows is None else int(rows)
+        if not 1 <= n_rows <= min(eng.max_batch, 16):
+            raise ValueError(f"rows must be in [1, {min(eng.max_batch, 16)}]")
+        it = iter(enumerate(requests))
+        slots = [None] * n_rows                 # per row: [request index, tokens so far, budget]
+        eng.decode_begin(torch.zeros(n_rows, dtype=torch.int32), [0] * n_rows, [0] * n_rows)       # every row parked
+        exhausted = False
+        while True:
+            for r in range(n_rows):             # admit requests into free rows
+                while slots[r] is None and not exhausted:
+                    try:
+                        idx, req = next(it)
+                    except StopIteration:
+                        exhausted = True
+                        break
+                    ids = req["input_ids"]
+                    ids = ids if ids.dim() == 2 else ids.unsqueeze(0)
+                    images = req.get("images")
+                    budget = int(req.get("max_new_tokens", max_new_tokens))
+                    if images is not None:
+                        images = images if isinstance(images, (list, tuple)) else [images]
+                        emb = self.prepare_inputs_labels_for_multimodal(ids.to(self.device), None, None, None, None, images,
+                                                                        req.get("images_size"))[4]
+                    else:
+                        emb = eng.embed_tokens(ids.to(self.device))
+                    S = emb.shape[1]
+                    if S + budget > eng.max_ctx:
+                        raise ValueError(f"request {idx}: prompt ({S}) + max_new_tokens ({budget}) exceeds the engine's max_ctx ({eng.max_ctx})")
+                    first = int(B.argmax(eng.prefill_rows(r, emb, [S]))[0])
+                    if first in eos or budget <= 1:
+                        yield idx, torch.tensor([first], dtype=torch.long)
+                        continue
+                    eng.decode_set_row(r, first, S, S)
+                    slots[r] = [idx, [first], budget]
+            if all(s is None for s in slots):
+                return
+            n = min([sync_every] + [s[2] - len(s[1]) for s in slots if s is not None])
+            chunk = eng.decode_steps(n).cpu()                           # [rows, n]; the only host sync of the chunk
+            for r, st in enumerate(slots):
+                if st is None:
+                    continue
+                for t in chunk[r].tolist():
+                    st[1].append(int(t))
+                    if int(t) in eos or len(st[1]) >= st[2]:
+                        break
+                if st[1][-1] in eos or len(st[1]) >= st[2]:
+                    yield st[0], torch.tensor(st[1], dtype=torch.long)
+                    eng.decode_set_row(r, 0, 0, 0)                       # park until the next request arrives
+                    slots[r] = None
+
     def _generate_one(self, embeds, position_ids, max_new, greedy, temperature, top_p, top_k, eos, streamer,
                       stopping_criteria, generator, sync_every, timing=None) -> List[int]:
         eng = self.engine

@@ -61,6 +61,8 @@ SYMBOLS = {
     "vz_qformer": (_I, [_P, _P, _I, _P, _I, _I, C.POINTER(C.c_int), _P, _P]),
     "vz_embed_splice": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "vz_llm_prefill": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int), _P, _P, _P, _P]),
+    "vz_llm_prefill_rows": (_I, [_P, _I, _P, _I, _I, C.POINTER(C.c_int), _P, _P, _P, _P]),
+    "vz_llm_decode_set_row": (_I, [_P, _I, _I, _I, _I, _P]),
     "vz_llm_decode_begin": (_I, [_P, _I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
     "vz_tune_set": (_I, [_I, _I]),

@@ -405,6 +405,22 @@ class Engine:
         B.check(self.lib.vz_llm_prefill(self.h, B.ptr(x), Bn, S, sl, B.ptr(pos), B.ptr(la), B.ptr(ll), self._s()))
         return la, ll
 
+    def prefill_rows(self, row0: int, embeds: torch.Tensor, seqlens: Sequence[int], position_ids: Optional[torch.Tensor] = None):
+        """`prefill` into KV-cache rows row0 .. row0+B-1 (continuous batching); returns the last-position logits fp32 [B,V]."""
+        x = embeds.to(self.device, torch.bfloat16).contiguous()
+        Bn, S = x.shape[0], x.shape[1]
+        if position_ids is None:
+            position_ids = torch.arange(S, dtype=torch.int32, device=self.device).unsqueeze(0).expand(Bn, S)
+        pos = position_ids.to(self.device, torch.int32).contiguous()
+        ll = torch.empty(Bn, self.cfg.vocab, dtype=torch.float32, device=self.device)
+        sl = (C.c_int * Bn)(*[int(v) for v in seqlens])
+        B.check(self.lib.vz_llm_prefill_rows(self.h, int(row0), B.ptr(x), Bn, S, sl, B.ptr(pos), None, B.ptr(ll), self._s()))
+        return ll
+
+    def decode_set_row(self, row: int, token: int, next_pos: int, ctx_len: int):
+        """(re)arm one row of the running decode batch; ctx_len 0 parks it."""
+        B.check(self.lib.vz_llm_decode_set_row(self.h, int(row), int(token), int(next_pos), int(ctx_len), self._s()))
+
     def decode_begin(self, first_ids: torch.Tensor, next_pos: Sequence[int], ctx_len: Sequence[int]):
         ids = first_ids.to(self.device, torch.int32).contiguous().view(-1)
         Bn = ids.numel()
