@@ -695,3 +695,42 @@ def test_continuous_batching_matches_static_batches(env):
         assert g1[0] == w[0] and len(g1) == len(w)           # (a 1-row step runs the GEMV: a near-tie may flip later tokens)
     del model
     torch.cuda.empty_cache()
+
+
+def test_stage1_shaped_batch_forward(env):
+    """BASELINE.json configs[3] (Stage-1 pretrain shape) without the tensor parallelism: one `forward` over a batch of 24 plain-
+    caption samples with 3..5 anyres tiles each (97 tiles, more than the engine holds at once -> tile chunks; more samples than
+    KV rows -> prefill chunks), labels in, loss out.  Rows must not depend on the batch around them: three of them are compared
+    with their single-sample forward, and the loss with the one recomputed from those logits."""
+    cfg, model, synth = env["cfg"], env["model"], env["synth"]          # env engine: max_batch 2, max_tiles 4, max_ctx 512
+    Bn = 24
+    n_tiles = [3 + (b * 7) % 3 for b in range(Bn)]
+    lens = [12 + (b * 5) % 17 for b in range(Bn)]
+    L = max(lens)
+    ids = torch.full((Bn, L), 2, dtype=torch.long)
+    mask = torch.zeros(Bn, L, dtype=torch.long)
+    labels = torch.full((Bn, L), -100, dtype=torch.long)
+    tiles = []
+    for b in range(Bn):
+        row = synth.synth_ids(lens[b], cfg.vocab, image_pos=1, seed=200 + b)        # plain caption: image right after BOS
+        ids[b, :lens[b]] = row
+        mask[b, :lens[b]] = 1
+        labels[b, 2:lens[b]] = row[2:]
+        tiles.append(synth.synth_tiles(n_tiles[b], seed=300 + b).to(model.device).bfloat16())
+    out = model(input_ids=ids.to(model.device), attention_mask=mask.to(model.device), labels=labels.to(model.device), images=tiles)
+    Smax = max(lens[b] - 1 + 32 * n_tiles[b] for b in range(Bn))
+    assert out.logits.shape == (Bn, Smax, cfg.vocab) and bool(torch.isfinite(out.loss))
+    for b in (0, 11, 23):
+        # alone, but with the SAME padded ids: the reference conditions the Q-Former on input_ids[i] pads included and without a
+        # key-padding mask (SURVEY Appendix A Q3/Q4), so a sample's visual tokens depend on the padded length of its batch
+        one = model(input_ids=ids[b:b + 1].to(model.device), attention_mask=mask[b:b + 1].to(model.device), images=[tiles[b]]).logits[0]
+        S = lens[b] - 1 + 32 * n_tiles[b]
+        # two valid bf16 paths (the tile GEMMs see different row counts -> different split-K / stream-K sums) decorrelate to the bf16
+        # band of the logits (~1.5e-2, test_forward_logits_case_a); a wrong sample map or cache row gives O(1)
+        check_close(f"stage-1 batch row {b} vs alone", out.logits[b, :S], one[:S], 6e-2, 2.5e-2)
+    # the loss is the mean token cross-entropy over the caption positions of the spliced sequences
+    _, _, _, _, _, lab = model.prepare_inputs_labels_for_multimodal(ids.to(model.device), None, mask.to(model.device), None,
+                                                                    labels.to(model.device), tiles)
+    ref = torch.nn.functional.cross_entropy(out.logits[:, :-1].reshape(-1, cfg.vocab), lab[:, 1:].reshape(-1), ignore_index=-100)
+    assert abs(float(out.loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert int((lab != -100).sum()) == sum(l - 2 for l in lens)

@@ -33,6 +33,17 @@ class VisZephyrMetaModel:
         return vt[0] if isinstance(vt, list) else vt
 
 
+def _compact_samples(text_embeddings, tile_sample):
+    """a subset of the tiles references a subset of the samples: hand the Q-Former only those rows of the per-sample text table
+    (the engine wants n_samples <= tiles) with the map renumbered."""
+    used = sorted(set(tile_sample))
+    if len(used) == text_embeddings.shape[0]:
+        return text_embeddings, tile_sample
+    renum = {v: i for i, v in enumerate(used)}
+    idx = torch.tensor(used, device=text_embeddings.device)
+    return text_embeddings.index_select(0, idx), [renum[v] for v in tile_sample]
+
+
 class VisZephyrMetaForCausalLM:
     """Mixin with the multimodal entry points; the concrete class provides `engine`, `arch`, `config`,
     `device`, `get_model()`."""
@@ -47,8 +58,25 @@ class VisZephyrMetaForCausalLM:
         eng = getattr(self, "engine", None)
         if eng is not None and eng.tp_size > 1 and getattr(self, "tile_data_parallel", True):
             return self._encode_images_tile_dp(images, text_embeddings, tile_sample)
-        feats = self.get_model().get_vision_tower()(images)
-        return self.get_model().mm_projector(feats, text_embeddings=text_embeddings, tile_sample=tile_sample)
+        T = int(images.shape[0])
+        cap = eng.max_tiles if eng is not None else T
+        if T <= cap:
+            feats = self.get_model().get_vision_tower()(images)
+            return self.get_model().mm_projector(feats, text_embeddings=text_embeddings, tile_sample=tile_sample)
+        # more tiles than the engine's workspace holds at once (Stage-1 shape: 64 images x up to 5 tiles): tiles are independent
+        # units, so they go through in chunks of `max_tiles`; a chunk carries its own rows of the text table / tile -> sample map
+        outs = []
+        for t0 in range(0, T, cap):
+            t1 = min(T, t0 + cap)
+            if text_embeddings is None:
+                text, ts = None, None
+            elif tile_sample is None:
+                text, ts = text_embeddings[t0:t1], None
+            else:
+                text, ts = _compact_samples(text_embeddings, [int(v) for v in tile_sample[t0:t1]])
+            feats = self.get_model().get_vision_tower()(images[t0:t1])
+            outs.append(self.get_model().mm_projector(feats, text_embeddings=text, tile_sample=ts))
+        return torch.cat(outs, dim=0)
 
     def _encode_images_tile_dp(self, images, text_embeddings, tile_sample):
         """Every tile is an independent unit through CLIP, fusion and the Q-Former (the Q-Former conditions a tile on its
@@ -68,7 +96,7 @@ class VisZephyrMetaForCausalLM:
             elif tile_sample is None:                    # one text block per tile
                 text, ts = text_embeddings.index_select(0, idx.to(text_embeddings.device)), None
             else:                                        # one text block per sample + the tile -> sample map
-                text, ts = text_embeddings, [int(tile_sample[t]) for t in mine]
+                text, ts = _compact_samples(text_embeddings, [int(tile_sample[t]) for t in mine])
             feats = self.get_model().get_vision_tower()(images.index_select(0, idx))
             send[: len(mine)] = self.get_model().mm_projector(feats, text_embeddings=text, tile_sample=ts)
         got = eng.all_gather(send).view(eng.tp_size * per, self.arch.qf_queries, self.arch.hidden)
