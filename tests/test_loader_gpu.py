@@ -1,0 +1,91 @@
+"""`load_pretrained_model` end to end on the GPU (ref:vis_zephyr/model/builder.py:16-161): a checkpoint laid out
+the way the reference's loader expects it - Zephyr backbone shards in `model_base`, `config.json` + `mm_projector.bin` in
+`model_path`, an HF CLIP directory named by `mm_vision_tower` - holding the hash-generated weights, so the loaded model can be
+compared bit for bit with `from_synthetic`."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _Tok:            # stands in for the sentencepiece tokenizer (no tokenizer files offline): what the builder uses of it
+    def __init__(self, n):
+        self.n = n
+        self.added = []
+
+    def add_tokens(self, toks, special_tokens=False):
+        self.added += list(toks)
+        self.n += len(toks)
+        return len(toks)
+
+    def __len__(self):
+        return self.n
+
+
+@pytest.mark.parametrize("load_8bit", [False, True])
+def test_load_pretrained_model_matches_from_synthetic(tmp_path, monkeypatch, load_8bit):
+    from safetensors.torch import save_file
+    import transformers
+    from vz_hip import synth
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    from vis_zephyr.model.builder import load_pretrained_model
+    cfg = synth.ArchConfig(n_layers=1, vocab=300)
+    base, ckpt, clip = tmp_path / "zephyr-7b-beta", tmp_path / "vis-zephyr-7b-v1-pretrain", tmp_path / "clip-vit-large-patch14-336"
+    for d in (base, ckpt, clip):
+        d.mkdir()
+    llm, vit, proj = {}, {}, {}
+    for k, v in synth.iter_state_dict(cfg, 0, device="cuda"):
+        # matrices as a bf16 checkpoint stores them; vectors (biases, norm scales) in fp32, which is how the engine keeps them - so the
+        # loaded engine holds exactly the bytes from_synthetic produces
+        v = (v.to(torch.bfloat16) if v.dim() >= 2 else v.float()).cpu().contiguous()
+        if k.startswith("model.vision_tower.vision_tower."):
+            vit[k[len("model.vision_tower.vision_tower."):]] = v
+        elif k.startswith("model.mm_projector."):
+            proj[k] = v
+        else:
+            llm[k] = v
+    keys = sorted(llm)
+    save_file({k: llm[k] for k in keys[: len(keys) // 2]}, str(base / "model-00001-of-00002.safetensors"))
+    save_file({k: llm[k] for k in keys[len(keys) // 2:]}, str(base / "model-00002-of-00002.safetensors"))
+    save_file(vit, str(clip / "model.safetensors"))
+    json.dump({"crop_size": {"height": 336, "width": 336}, "size": {"shortest_edge": 336}, "image_mean": [0.48145466, 0.4578275, 0.40821073],
+               "image_std": [0.26862954, 0.26130258, 0.27577711], "image_processor_type": "CLIPImageProcessor", "resample": 3,
+               "do_resize": True, "do_center_crop": True, "do_normalize": True, "do_rescale": True, "do_convert_rgb": True},
+              open(clip / "preprocessor_config.json", "w"))
+    torch.save(proj, str(ckpt / "mm_projector.bin"))
+    json.dump({"model_type": "vis_zephyr", "architectures": ["VisZephyrForCausalLM"], "hidden_size": cfg.hidden, "intermediate_size": cfg.inter,
+               "num_hidden_layers": 1, "num_attention_heads": cfg.n_heads, "num_key_value_heads": cfg.n_kv_heads, "vocab_size": 300,
+               "rms_norm_eps": cfg.rms_eps, "rope_theta": cfg.rope_theta, "sliding_window": 4096, "mm_vision_tower": str(clip),
+               "mm_hidden_size": 5120, "mm_patch_merge_type": "flat", "image_aspect_ratio": "anyres", "mm_vision_select_feature": "patch",
+               "mm_vision_select_layer": "-2,-5,-8,-11,6", "mm_projector_type": "mlp2x_gelu", "eos_token_id": 2, "pad_token_id": 2,
+               "bos_token_id": 1}, open(ckpt / "config.json", "w"))
+    monkeypatch.setattr(transformers.AutoTokenizer, "from_pretrained", staticmethod(lambda *a, **k: _Tok(300)))
+    tok, model, proc, ctx = load_pretrained_model(str(ckpt), str(base), "vis-zephyr-7b-v1-pretrain", load_8bit=load_8bit, max_ctx=256)
+    assert ctx == 2048 and len(tok) == 301 and tok.added == ["<im_patch>"]        # ref builder.py:141-153: vocabulary grows by one
+    assert model.config.vocab_size == 301 and model.engine.cfg.vocab == 301 and model.engine.weight_fp8 == load_8bit
+    assert proc is not None and proc.crop_size["height"] == 336
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=1, num_attention_heads=cfg.n_heads,
+                         num_key_value_heads=cfg.n_kv_heads, vocab_size=300, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+                         sliding_window=4096, eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = str(clip)
+    hf.mm_patch_merge_type = "flat"
+    hf.mm_hidden_size = 5120
+    ref = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=256, max_tiles=2, max_text=64, weight_fp8=load_8bit)
+    tiles = synth.synth_tiles(2, seed=1).to(model.device).bfloat16()
+    ids = synth.synth_ids(20, 300, image_pos=3, seed=2).unsqueeze(0).to(model.device)
+    diff = [n for n, t in ref.engine.w.items() if not n.startswith(("llm.embed", "llm.lm_head")) and not torch.equal(t, model.engine.w[n])]
+    assert not diff, f"engine tensors differ after loading: {diff[:8]} ({len(diff)} of {len(ref.engine.w)})"
+    a = model(input_ids=ids, images=[tiles]).logits
+    b = ref(input_ids=ids, images=[tiles]).logits
+    # same weights and kernels up to the lm_head GEMM, whose split-K form needs N % 4 == 0 (300 rows: yes, 301: no): the fp32
+    # logits agree to re-association of the K sum
+    assert a.shape[-1] == 301 and float((a[..., :300] - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    # the added row is the mean of the old lm_head rows (what resize_token_embeddings gives; vz_hip/weights.py::resize_vocab)
+    if not load_8bit:
+        lm = ref.engine.w["llm.lm_head"].float()
+        assert torch.equal(model.engine.w["llm.lm_head"][300].float(), lm[:300].mean(0).bfloat16().float())
+    out = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=4, eos_token_id=None)
+    assert out.shape == (1, 4)
