@@ -826,12 +826,13 @@ extern "C" int vz_llm_decode_set_row(vz_engine* e, int row, int token, int next_
     VZ_CHECK_ARG(e->dec_B >= 1 && row >= 0 && row < e->dec_B, "decode_set_row: row %d outside the running batch of %d", row, e->dec_B);
     VZ_CHECK_ARG(ctx_len >= 0 && ctx_len < c.max_ctx && next_pos >= 0, "decode_set_row: ctx_len %d / pos %d outside [0,%d)", ctx_len, next_pos, c.max_ctx);
     const int mb = c.max_batch;
-    const int h[4] = {token, next_pos, ctx_len, ctx_len + 1};     // cur | pos | slot | len
+    const int h[4] = {token, next_pos, ctx_len, ctx_len + 1};     // cur | pos | slot | len: one int in each of the four state arrays
     hipStream_t s = (hipStream_t)stream;
-    for (int k = 0; k < 4; ++k) {
-        // four 4-byte updates through the pinned staging path of upload_ints (stream-ordered, safe against a following launch)
-        RC(upload_ints(e, &h[k], 1, e->d_state + k * mb + row, s));
-    }
+    VZ_CHECK_ARG(e->h_pinned && e->h_pinned_ints >= 4, "decode_set_row: no staging buffer (vz_llm_decode_begin allocates it)");
+    VZ_CHECK_HIP(hipStreamSynchronize(s));                        // previous use of the staging buffer has drained
+    memcpy(e->h_pinned, h, sizeof(h));
+    // a 4-row x 4-byte strided copy: row k lands in state array k at column `row`
+    VZ_CHECK_HIP(hipMemcpy2DAsync(e->d_state + row, (size_t)mb * sizeof(int), e->h_pinned, sizeof(int), sizeof(int), 4, hipMemcpyHostToDevice, s));
     return VZ_OK;
 }
 
