@@ -458,7 +458,11 @@ def test_fp8_weight_engine_matches_quantized_oracle(env):
     check_close("fp8 last-row logits (GEMV) vs all-rows (GEMM)", last[0], full[0, S0 - 1], 3e-2, 6e-3)
     eng.decode_begin(ids[S0:S0 + 1].to(torch.int32), [S0], [S0])
     _, lg = eng.decode_steps(1, return_logits=True)
-    check_close("fp8 decode step vs prefill", lg[0, 0], full[0, S0], 3e-2, 6e-3)
+    # the decode step (GEMV/skinny weight stream, split softmax) and the prefill row (MFMA GEMMs, flash
+    # attention) are two bf16 evaluation orders of the same network: they sit inside the same band the
+    # oracle's own bf16-vs-fp32 distance defines, not inside a hand-picked constant
+    e_or = errs(lo_bf, lo_32)[1]
+    check_close("fp8 decode step vs prefill", lg[0, 0], full[0, S0], 3e-2, 1.6 * e_or + 5e-4)
     # greedy generation against the quantised-weight oracle
     n_new = 6
     got = model.generate(input_ids=ids.unsqueeze(0), do_sample=False, max_new_tokens=n_new, eos_token_id=None, pad_token_id=2)

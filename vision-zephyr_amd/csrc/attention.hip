@@ -132,8 +132,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(FlashParams p) {
                 sacc[nt][r] = s;
                 m_tile = fmaxf(m_tile, s);
             }
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+        m_tile = rows_max(m_tile);
         const float m_new = fmaxf(m_run, m_tile);
         const float m_safe = m_new == -INFINITY ? 0.f : m_new;
         const float alpha = __expf(m_run - m_safe);  // m_run = -inf -> 0
@@ -146,8 +145,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(FlashParams p) {
                 sacc[nt][r] = e;
                 psum += e;
             }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
+        psum = rows_sum(psum);
         l_run = l_run * alpha + psum;
         m_run = m_new;
 #pragma unroll
@@ -206,6 +204,7 @@ __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
     return __builtin_bit_cast(bf16x4, v);
 }
 
+// The row statistics of a query live in lanes c, c+16, c+32, c+48: rows_max / rows_sum (vz_common.h) all-reduce them on the VALU.
 // Online-softmax step of one 16-query tile.  FULL = every key of the tile is visible to every query of the wave
 // (no padding, not on the causal diagonal, inside the window): the mask arithmetic is skipped - wave-uniform choice,
 // identical values.  exp(x) is evaluated as exp2(x * log2e) on pre-scaled scores: one FMA + v_exp_f32 per element.
@@ -227,8 +226,7 @@ __device__ __forceinline__ void softmax_tile(f32x4 (&sacc)[NT], float& m_run, fl
             sacc[nt][r] = sv;
             m_tile = fmaxf(m_tile, sv);
         }
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    m_tile = rows_max(m_tile);
     const float m_new = fmaxf(m_run, m_tile);
     const float m_safe = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
@@ -241,8 +239,7 @@ __device__ __forceinline__ void softmax_tile(f32x4 (&sacc)[NT], float& m_run, fl
             sacc[nt][r] = e;
             psum += e;
         }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
+    psum = rows_sum(psum);
     l_run = l_run * alpha + psum;
     m_run = m_new;
     if (!__all(alpha == 1.0f)) {      // the running maximum did not move for any query of the wave: nothing to rescale

@@ -27,32 +27,54 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-// Sum over the 64 lanes with DPP moves (VALU, 4 cycles each) instead of ds_bpermute shuffles (an LDS round trip each): the
-// total is valid in LANE 63 ONLY.  quad swaps, half-row / row mirrors (each 16-lane row then holds its sum in every lane), then
-// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.
+// ---- wave-wide reductions on the VALU (gfx950) ----
+// Inside a 16-lane row: DPP moves (quad swaps, half-row mirror, row mirror) - after the four steps every lane of a row holds
+// its row's result.  Across the four rows: v_permlane16_swap (odd rows of one operand <-> even rows of the other) and
+// v_permlane32_swap (wave halves); with both operands = v the pair is (r0,r0,r2,r2) / (r1,r1,r3,r3) resp. (lo,lo) / (hi,hi), so
+// one op() of the pair is the xor-16 resp. xor-32 butterfly step.  Six VALU steps instead of six ds_bpermute round trips
+// through the LDS pipeline; the result is valid in EVERY lane.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-    return v + __int_as_float(moved);
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ float wave_sum_lane63(float v) {
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) { return v + dpp_mov<CTRL, ROW_MASK>(v); }
+
+__device__ __forceinline__ float rows_sum(float v) {       // all-reduce over lanes c, c+16, c+32, c+48
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float rows_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add<0xb1, 0xf>(v);      // quad_perm:[1,0,3,2]
     v = dpp_add<0x4e, 0xf>(v);      // quad_perm:[2,3,0,1]
     v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
     v = dpp_add<0x140, 0xf>(v);     // row_mirror
+    return rows_sum(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_mov<0xb1, 0xf>(v));
+    v = fmaxf(v, dpp_mov<0x4e, 0xf>(v));
+    v = fmaxf(v, dpp_mov<0x141, 0xf>(v));
+    v = fmaxf(v, dpp_mov<0x140, 0xf>(v));
+    return rows_max(v);
+}
+// sum valid in LANE 63 ONLY (row_bcast:15 / row_bcast:31 instead of the two swaps: one instruction less per value when many
+// values are reduced at once, as the GEMV epilogue does)
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v = dpp_add<0xb1, 0xf>(v);
+    v = dpp_add<0x4e, 0xf>(v);
+    v = dpp_add<0x141, 0xf>(v);
+    v = dpp_add<0x140, 0xf>(v);
     v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 -> rows 1, 3
     v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 -> rows 2, 3
-    return v;
-}
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 
