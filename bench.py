@@ -129,6 +129,7 @@ def main():
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
+    tune = os.environ.get("VZ_TUNE", "")   # experiments only: "knob=value,..." for vz_tune_set; reported in config when set
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
@@ -148,6 +149,9 @@ def main():
     torch.cuda.set_device(device)
 
     from vz_hip import binding as B, synth
+    for kv in filter(None, tune.split(",")):
+        k, v = kv.split("=")
+        B.check(B.lib().vz_tune_set(int(k), int(v)))
     n_tiles, n_ids, n_new = 5, 1889, args.new_tokens
     S = (n_ids - 1) + 32 * n_tiles
     # N > 1: replicas by default (one request per GPU, weak scaling).  VZ_BENCH_PARALLELISM=tp runs ONE request over a
@@ -327,6 +331,8 @@ def main():
                                                                           else f"dp{world} replicas (one request per GPU, no collective)")},
         "roofline": roof, "roofline_prefill": roof_prefill, "cpu_baseline": cpu,
     }
+    if tune:
+        line["config"]["tune"] = tune
     if tp_leg is not None:
         line["tensor_parallel"] = tp_leg
     if fp8_leg is not None:

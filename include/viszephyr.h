@@ -246,7 +246,8 @@ int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_strea
  * compiled into the library: rows per wave, chunks in flight, non-temporal loads), 1 = GEMM kernel choice,
  * 2 = prefill attention generation, 3 = split-K mode, 4 = 256^2 GEMM stream-K tail (1 = on, 0 = whole tiles only), 5 = stream-K skew in K-tiles, 6 = record 256^2 GEMM phase stamps,
  * 7 = route the collectives of a tp_size == 1 engine that holds a one-rank communicator through RCCL (self-test),
- * 9 = 2..16-row linears (1 = MFMA weight stream, 0 = GEMV / tile GEMM).
+ * 9 = 2..16-row linears (1 = MFMA weight stream, 0 = GEMV / tile GEMM), 10 = context splits of the fused decode attention
+ * (0 = engine default, 1..64).
  * Process-wide. */
 int vz_tune_set(int knob, int value);
 

@@ -329,9 +329,11 @@ def test_attention_decode_fused_equals_rope_plus_decode(B, ctx, nsplit, window):
 
 
 # (520, 1024, 8192): 12 tiles x 128 K-tiles -> 8 K-slices per tile; (700, 1300, 4160): 18 tiles x 65 K-tiles cut unevenly;
-# (1, 32001, 512): workgroups that run two whole tiles each; (2048, 28672, 4096): 3 full rounds + a split half round
+# (1, 32001, 512): workgroups that run two whole tiles each; (2048, 28672, 4096): 3 full rounds + a split half round;
+# (2885, ...), (3291, 1100, 256), (5000, 300, 128): more than 8 row tiles -> grouped tile order with a short last group (4, 5, 4 rows)
 GEMM256_SHAPES = [(2048, 6144, 4096), (2048, 4096, 14336), (2885, 4096, 1024), (300, 520, 128), (256, 256, 64), (257, 255, 192),
-                  (1, 32001, 512), (2048, 28672, 4096), (2048, 4096, 4096), (520, 1024, 8192), (700, 1300, 4160)]
+                  (1, 32001, 512), (2048, 28672, 4096), (2048, 4096, 4096), (520, 1024, 8192), (700, 1300, 4160),
+                  (3291, 1100, 256), (5000, 300, 128)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM256_SHAPES)

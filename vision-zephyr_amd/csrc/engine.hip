@@ -614,6 +614,7 @@ extern "C" int vz_embed_splice(vz_engine* e, const int* d_kind, const int* d_idx
 // call sites through RCCL (all-reduce over one rank = identity, all-gather = copy), so the collective plumbing - library,
 // dtypes, in-place buffers, stream order, the vocab-parallel gather + repack - runs on a single GPU.
 static int g_force_comm = 0;
+static int g_attn_nsplit = 0;   // vz_tune_set(10, n): context splits of the fused decode attention (0 = engine default)
 static inline bool tp_local(const vz_engine* e) { return e->tp == 1 && !(g_force_comm && e->comm); }
 
 // vz_tune_set(7, 2): shape rehearsal of ONE rank of a tp_size > 1 engine on a single GPU - every collective is skipped (the
@@ -860,7 +861,7 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
             AttnDecodeFusedArgs a;
             a.qkv = qkv; a.kc = kc_of(e, i); a.vc = vc_of(e, i); a.o = att; a.part = e->d_part; a.ticket = e->d_ticket;
             a.cosT = e->cosT; a.sinT = e->sinT; a.pos = pos; a.slot = slot;
-            a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_ctx = c.max_ctx; a.nsplit = e->nsplit; a.window = c.sliding_window;
+            a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_ctx = c.max_ctx; a.nsplit = g_attn_nsplit > 0 ? g_attn_nsplit : e->nsplit; a.window = c.sliding_window;
             a.scale = 0.08838834764831845f;
             RC(vz_launch_attn_decode_fused(a, s));
         }
@@ -935,6 +936,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 6) { g_gemm256_stamps = value; return VZ_OK; }
     if (knob == 7) { g_force_comm = value; return VZ_OK; }
     if (knob == 9) { g_skinny_mode = value; return VZ_OK; }
+    if (knob == 10) { if (value < 0 || value > 64) { vz_set_error("tune_set: decode attention splits must be 0..64"); return VZ_ERR_ARG; } g_attn_nsplit = value; return VZ_OK; }
     vz_set_error("tune_set: unknown knob %d", knob);
     return VZ_ERR_ARG;
 }

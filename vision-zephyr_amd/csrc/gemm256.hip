@@ -311,7 +311,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
             tile = p.n_full + tr;
         }
         const int nks = k1 - k0;
-        const int bn = tile / p.tiles_m, bm = tile - bn * p.tiles_m;
+        // tile index -> (bm, bn): row tiles in groups of 8, columns inside a group, rows fastest.  The 32 workgroups an XCD runs at
+        // a time (consecutive indices) then cover 8 row panels x 4 column panels (12 operand panels through its L2 instead of
+        // 33 when M is many tiles tall: the Q-Former K/V projection of 80 tiles re-read A 32 times).  tiles_m <= 8: plain
+        // column-major, as before.
+        const int per_group = 8 * p.tiles_n, grp = tile / per_group, in_grp = tile - grp * per_group;
+        const int gsz = p.tiles_m - grp * 8 < 8 ? p.tiles_m - grp * 8 : 8;
+        const int bn = in_grp / gsz, bm = grp * 8 + (in_grp - bn * gsz);
 
         // ---- staging sources: half-tile X_h, instruction j -> LDS chunk ch = j*512 + tid (row ch>>3, slot ch&7) ----
         const char* src[4][2];   // [A_0, A_1, B_0, B_1][j]
