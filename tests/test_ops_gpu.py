@@ -553,6 +553,43 @@ def test_skinny_gemm_fused_rmsnorm(B, M, act):
         check_close(f"gemv vs skinny fused norm M{M}", gv, out, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("M,N,act", [(5, 6144, 0), (16, 6144, 3), (16, 28672, 3), (9, 32001, 0), (12, 4000, 1), (16, 48, 0)])
+def test_skinny_persistent_fused_norm(B, M, N, act):
+    """5..16 rows with the RMSNorm fused: ONE workgroup per CU stages the normalised rows in LDS once and walks its row groups
+    (weight prefetch running across group boundaries).  Same K-slices and slice order as the one-group-per-workgroup kernel
+    (knob 9 = 2 routes the same call there): bit-identical where that kernel also runs 8 waves per group (< 512 groups),
+    fp32-close beyond (4-wave groups there); ragged N (lm_head 32001), fewer groups than CUs (48), fp8 rows."""
+    K = 4096
+    x = _rand((M, K), 3.0, 204).bfloat16()
+    nw = _rand((K,), 0.2, 205) + 1.0
+    w = _rand((N, K), 0.02, 206).bfloat16()
+    xf = bf16r(x).double()
+    xn = (nw.double() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))).float().bfloat16()
+    groups = N // 32 if act == 3 else (N + 15) // 16
+    for rep in range(3):
+        out = B.linear_rmsnorm(x, nw, 1e-5, w, act=act, out_fp32=True)
+        if rep == 0:
+            first = out.clone()
+            check_close(f"persistent skinny M{M} N{N} act{act}", out, _ref_linear(xn, w, None, None, act), 2e-2, 3e-3)
+        assert torch.equal(out, first), "result changed between launches"
+        torch.randn(1 << 21, device="cuda").sum()
+    try:
+        B.check(B.lib().vz_tune_set(9, 2))
+        old = B.linear_rmsnorm(x, nw, 1e-5, w, act=act, out_fp32=True)
+    finally:
+        B.check(B.lib().vz_tune_set(9, 1))
+    if groups < 512:
+        assert torch.equal(old, first), f"{(old != first).sum().item()} elements differ from the one-group-per-workgroup kernel"
+    else:
+        check_close(f"persistent vs 4-wave groups M{M} N{N}", first, old, 1e-4, 1e-4)
+    if act != 3 or N % 64 == 0:
+        from vz_hip import quant
+        w8, ws = quant.quantize_rows(w)
+        wq = quant.dequantize_rows(w8, ws).bfloat16()
+        o8 = B.linear_fp8(x, w8, ws, act=act, out_fp32=True, norm_w=nw, norm_eps=1e-5)         # e4m3 rows widened in registers (exact)
+        check_close(f"persistent skinny fp8 M{M} N{N}", o8, B.linear_rmsnorm(x, nw, 1e-5, wq, act=act, out_fp32=True), 1e-4, 1e-4)
+
+
 # ---- seeded shape fuzz through the PRODUCTION dispatch: every kernel family must agree with the fp64 reference at shapes
 # ---- nobody tuned for (ragged M / N, odd tile counts, grids that do not divide the CU count, every epilogue) ----
 def _fuzz_linear_cases(n=28, seed=1234):

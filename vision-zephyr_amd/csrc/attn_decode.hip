@@ -64,7 +64,11 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(FusedParams p) {
     const int slot = p.slot[b], len = slot + 1, position = p.pos[b];
     const int lo = p.window > 0 ? max(0, len - p.window) : 0;
     const int span = len - lo;
-    const int per = (span + p.nsplit - 1) / p.nsplit;
+    // a split takes at least one chunk: a short context (a 16-row batch at ctx 100) is served by ONE workgroup per KV head
+    // and row instead of nsplit mostly empty ones all running the ticket protocol; the others leave at once
+    const int per = max(CH, (span + p.nsplit - 1) / p.nsplit);
+    const int n_active = (span + per - 1) / per;
+    if (split >= n_active) return;
     const int k0 = lo + split * per, k1 = min(len, k0 + per);
     const int heads = p.Hq + 2 * p.Hkv;
     const bf16_t* row = p.qkv + (size_t)b * heads * D;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(FusedParams p) {
     __syncthreads();
     if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(p.ticket + (size_t)b * p.Hkv + hk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = (t == (unsigned)p.nsplit - 1) ? 1u : 0u;
+        last_flag = (t == (unsigned)n_active - 1) ? 1u : 0u;
     }
     __syncthreads();   // the wave that added joins this barrier after its add returned; everyone loads behind it
     if (!last_flag) return;
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(FusedParams p) {
     {
         const int h = tid >> 6, s2 = tid & 63;
         float ms = -INFINITY, ls = 0.f;
-        if (s2 < p.nsplit) { ms = ld_sc1(pp + (size_t)s2 * PW + G * D + h); ls = ld_sc1(pp + (size_t)s2 * PW + G * D + G + h); }
+        if (s2 < n_active) { ms = ld_sc1(pp + (size_t)s2 * PW + G * D + h); ls = ld_sc1(pp + (size_t)s2 * PW + G * D + G + h); }
         const float m = wave_max(ms);
         const float w = ms == -INFINITY ? 0.f : __expf(ms - m);
         const float l = wave_sum(w * ls);
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(FusedParams p) {
         const int h = i >> 7;
         float a = 0.f;
 #pragma unroll 8
-        for (int s2 = 0; s2 < p.nsplit; ++s2) a += wgt[h * 64 + s2] * ld_sc1(pp + (size_t)s2 * PW + i);
+        for (int s2 = 0; s2 < n_active; ++s2) a += wgt[h * 64 + s2] * ld_sc1(pp + (size_t)s2 * PW + i);
         p.o[((size_t)b * p.Hq + hk * G) * D + i] = f32_to_bf16(a * wgt[G * 64 + h]);
     }
     if (tid == 0) __hip_atomic_store(p.ticket + (size_t)b * p.Hkv + hk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

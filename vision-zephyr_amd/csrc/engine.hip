@@ -14,6 +14,7 @@
 // so the engine computes block 0's self-attention once per SAMPLE for the 32 query rows (K/V over
 // all 32+L rows) and runs cross-attention/FFN per tile on 32 rows - identical results, without the
 // rows the reference computes and throws away.
+#include <algorithm>
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -158,13 +159,15 @@ struct vz_engine {
     // decode state (device)
     int* d_state = nullptr;  // [cur_ids[B] | pos[B] | slot[B] | len[B] | step]
     int dec_B = 0;
+    int dec_len_max = 0;         // host-side bound on the longest row's visible keys (grows by one per launched step)
+    int dec_nsplit = 1;          // context splits of the decode attention for the steps being launched
     float* d_logits = nullptr;   // [max_batch, vocab] fp32
     bf16_t* d_xnorm = nullptr;   // [16, hidden]: normalised rows of a 5..16-row decode batch (the MFMA weight stream reads them from L2)
     float* d_part = nullptr;     // decode attention partials
     unsigned* d_ticket = nullptr; // arrival counters of the fused decode attention
-    int nsplit = 16;
+    int nsplit = 32;                 // upper bound: a split takes >= 128 keys, the splits beyond ceil(len / 128) leave at once
     hipStream_t cap_stream = nullptr;   // stream capture is not allowed on the legacy null stream torch hands us
-    hipGraphExec_t dec_graph = nullptr; int dec_graph_B = 0, dec_graph_n = 0; int* dec_graph_out = nullptr; char* dec_graph_arena = nullptr;
+    hipGraphExec_t dec_graph = nullptr; int dec_graph_B = 0, dec_graph_n = 0, dec_graph_nsplit = 0; int* dec_graph_out = nullptr; char* dec_graph_arena = nullptr;
     int* h_pinned = nullptr;     // pinned staging for small host->device uploads
     size_t h_pinned_ints = 0;
     // profiling
@@ -229,9 +232,9 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
         a.W8 = W8; a.wscale = ws;
         if (!vz_gemv_ok(a) && !(g_skinny_mode && vz_skinny_ok(a))) { a.W8 = nullptr; a.wscale = nullptr; }
     }
-    if (norm_w && M > 4 && K == e->c.hidden && g_skinny_mode) {
-        // 5..16 rows: staging the normalised rows in LDS (M x 8 KiB) would leave one workgroup per CU; normalise once into
-        // an L2-resident scratch instead and let the MFMA weight stream take its B fragments from there
+    if (norm_w && M > 4 && K == e->c.hidden && g_skinny_mode && !(vz_skinny_ok(a) && vz_skinny_fused_norm_ok(a))) {
+        // 5..16 rows without the persistent fused-norm kernel (knob 9 = 2, or a K it does not take): normalise once into an
+        // L2-resident scratch and let the one-group-per-workgroup MFMA weight stream take its B fragments from there
         { ProfScope ps(e, K_NORM, s); int r = vz_launch_rmsnorm(A, lda, e->d_xnorm, K, norm_w, M, K, norm_eps, s); if (r) return r; }
         a.A = e->d_xnorm; a.lda = K; a.norm_w = nullptr;
         if (vz_skinny_ok(a)) { ProfScope ps(e, K_GEMV, s); return vz_launch_skinny(a, s); }
@@ -815,6 +818,8 @@ extern "C" int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, 
     RC(upload_ints(e, h.data(), h.size(), e->d_state + mb, s));   // [pos | slot | len | step=0]
     VZ_CHECK_HIP(hipMemcpyAsync(e->d_state, d_first_ids, B * sizeof(int), hipMemcpyDeviceToDevice, s));
     e->dec_B = B;
+    e->dec_len_max = 0;
+    for (int b = 0; b < B; ++b) e->dec_len_max = std::max(e->dec_len_max, h_ctx_len[b] + 1);
     return VZ_OK;
 }
 
@@ -828,6 +833,7 @@ extern "C" int vz_llm_decode_set_row(vz_engine* e, int row, int token, int next_
     VZ_CHECK_ARG(ctx_len >= 0 && ctx_len < c.max_ctx && next_pos >= 0, "decode_set_row: ctx_len %d / pos %d outside [0,%d)", ctx_len, next_pos, c.max_ctx);
     const int mb = c.max_batch;
     const int h[4] = {token, next_pos, ctx_len, ctx_len + 1};     // cur | pos | slot | len: one int in each of the four state arrays
+    e->dec_len_max = std::max(e->dec_len_max, ctx_len + 1);
     hipStream_t s = (hipStream_t)stream;
     VZ_CHECK_ARG(e->h_pinned && e->h_pinned_ints >= 4, "decode_set_row: no staging buffer (vz_llm_decode_begin allocates it)");
     VZ_CHECK_HIP(hipStreamSynchronize(s));                        // previous use of the staging buffer has drained
@@ -861,7 +867,7 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
             AttnDecodeFusedArgs a;
             a.qkv = qkv; a.kc = kc_of(e, i); a.vc = vc_of(e, i); a.o = att; a.part = e->d_part; a.ticket = e->d_ticket;
             a.cosT = e->cosT; a.sinT = e->sinT; a.pos = pos; a.slot = slot;
-            a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_ctx = c.max_ctx; a.nsplit = g_attn_nsplit > 0 ? g_attn_nsplit : e->nsplit; a.window = c.sliding_window;
+            a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_ctx = c.max_ctx; a.nsplit = e->dec_nsplit; a.window = c.sliding_window;
             a.scale = 0.08838834764831845f;
             RC(vz_launch_attn_decode_fused(a, s));
         }
@@ -901,13 +907,27 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     const bool use_graph = !e->prof_on && !d_logits_dbg && tp_local(e) && getenv("VZ_NO_GRAPH") == nullptr;   // collectives run eagerly
     int* step = e->d_state + 4 * c.max_batch;
     VZ_CHECK_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
+    // Context splits of the decode attention = grid.x: a split takes >= 128 keys and workgroups that find nothing to do still cost
+    // a dispatch slot each (measured: 4096 mostly idle workgroups = 59 us per layer at 16 rows), so the grid follows the longest
+    // context these n steps can reach - known on the host - in coarse buckets (a new bucket = one re-capture of the graph).
+    {
+        int keys = std::min(e->dec_len_max + n, c.max_ctx);
+        if (c.sliding_window > 0) keys = std::min(keys, c.sliding_window);
+        const int need = (keys + 127) / 128;
+        static const int buckets[] = {1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 24, 28, 32};
+        int ns = e->nsplit;
+        for (int bk : buckets) if (bk >= need) { ns = std::min(bk, e->nsplit); break; }
+        e->dec_nsplit = g_attn_nsplit > 0 ? g_attn_nsplit : ns;
+        e->dec_len_max += n;
+    }
     if (!use_graph) {
         for (int i = 0; i < n; ++i)
             RC(decode_step_launch(e, d_out_ids, n, d_logits_dbg ? d_logits_dbg + (size_t)i * B * c.vocab : nullptr, s));
         return VZ_OK;
     }
     // Output pointer / stride and the workspace are kernel arguments frozen in the graph: re-capture when they change.
-    if (!e->dec_graph || e->dec_graph_B != B || e->dec_graph_n != n || e->dec_graph_out != d_out_ids || e->dec_graph_arena != e->arena) {
+    if (!e->dec_graph || e->dec_graph_B != B || e->dec_graph_n != n || e->dec_graph_out != d_out_ids || e->dec_graph_arena != e->arena ||
+        e->dec_graph_nsplit != e->dec_nsplit) {
         if (e->dec_graph) { hipGraphExecDestroy(e->dec_graph); e->dec_graph = nullptr; }
         hipGraph_t graph;
         if (!e->cap_stream) VZ_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
@@ -918,7 +938,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
         VZ_CHECK_HIP(er);
         VZ_CHECK_HIP(hipGraphInstantiate(&e->dec_graph, graph, nullptr, nullptr, 0));
         hipGraphDestroy(graph);
-        e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena;
+        e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena; e->dec_graph_nsplit = e->dec_nsplit;
     }
     for (int i = 0; i < n; ++i) VZ_CHECK_HIP(hipGraphLaunch(e->dec_graph, s));
     return VZ_OK;

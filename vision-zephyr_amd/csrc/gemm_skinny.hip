@@ -206,6 +206,162 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     }
 }
 
+// Persistent form of the fused-norm variant (QKV, gate-up, lm_head of a 2..16-row decode step): one 8-wave workgroup per CU
+// stages the normalised activation rows in LDS ONCE and then walks its row groups (blockIdx.x, + gridDim.x, ...), so x is read
+// 256 times per launch instead of once per row group (gate-up: 896 groups, lm_head: 2000) and never competes with the weight
+// stream for L2.  The weight loads run U steps ahead of the MFMAs ACROSS group boundaries (slot u is refilled right after it is
+// consumed, possibly with the next group's first steps), so the reduction / epilogue of a group hides under the loads in flight.
+// Same k assignment, same per-wave K-slices and the same summation order over the eight slices as skinny_kernel: results are
+// bit-identical to it.  Needs K/64 divisible by 8 waves x U steps (hidden 4096: 64 steps = 8 x 8).
+template <bool SWIGLU, bool FP8>
+__global__ __launch_bounds__(512) void skinny_persist_kernel(SkinnyParams p, int n_groups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 8;
+    constexpr int U = SWIGLU ? 4 : 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int K = p.K;
+    const int xs_stride = K + 8;
+    bf16_t* xs = (bf16_t*)smem;                                           // [M][K + 8]
+    float* red = (float*)(smem + (size_t)p.M * xs_stride * 2);            // [NW][2][64][4]
+    const int per = (K >> 6) / NW;                                        // steps per wave and group (host: exact, multiple of U)
+    const int s0 = wave * per;
+    const int G = (n_groups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // my groups (grid <= n_groups)
+    const bool row_ok = fr < p.M;
+
+    u32x4 qa[U][2], qb[U][2];
+    int pj = 0, ps = 0;                                                   // prefetch cursor: my group ordinal, step within the slice
+    auto refill = [&](int u) {
+        if (pj < G) {
+            const int grp = blockIdx.x + pj * gridDim.x;
+            int row_a, row_b = 0;
+            if (SWIGLU) { row_a = grp * 32 + fr; row_b = row_a + 16; }
+            else { row_a = grp * 16 + fr; row_a = row_a < p.N ? row_a : p.N - 1; }
+            const size_t koff = (size_t)(s0 + ps) * 64 + g * 16;
+            if (FP8) {
+                qa[u][0] = *(const u32x4*)(p.W8 + (size_t)row_a * p.ldw + koff);
+                if (SWIGLU) qb[u][0] = *(const u32x4*)(p.W8 + (size_t)row_b * p.ldw + koff);
+            } else {
+                const u32x4* pa = (const u32x4*)(p.W + (size_t)row_a * p.ldw + koff);
+                qa[u][0] = pa[0]; qa[u][1] = pa[1];
+                if (SWIGLU) {
+                    const u32x4* pb = (const u32x4*)(p.W + (size_t)row_b * p.ldw + koff);
+                    qb[u][0] = pb[0]; qb[u][1] = pb[1];
+                }
+            }
+            if (++ps == per) { ps = 0; ++pj; }
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) refill(u);          // the first weights are in flight before the norm prologue
+
+    for (int m = wave; m < p.M; m += NW) {          // one wave per activation row: bf16(norm_w * x * rstd) -> LDS
+        const bf16_t* x = p.A + (size_t)m * p.lda;
+        float ss = 0.f;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            const u16x8 v = *(const u16x8*)(x + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(v[j]); ss += f * f; }
+        }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)K + p.norm_eps);
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            const u16x8 v = *(const u16x8*)(x + k);
+            const f32x4 w0 = *(const f32x4*)(p.norm_w + k), w1 = *(const f32x4*)(p.norm_w + k + 4);
+            u16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float wj = j < 4 ? w0[j] : w1[j - 4];
+                o[j] = f32_to_bf16(wj * (bf16_to_f32(v[j]) * rstd));
+            }
+            *(u16x8*)(xs + (size_t)m * xs_stride + k) = o;
+        }
+    }
+    __syncthreads();
+
+    const bf16_t* xl = xs + (size_t)(row_ok ? fr : 0) * xs_stride + g * 16;
+    const int n_out_total = SWIGLU ? p.N / 2 : p.N;
+    for (int j = 0; j < G; ++j) {
+        f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+        for (int i0 = 0; i0 < per; i0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const u32x4* px = (const u32x4*)(xl + (size_t)(s0 + i0 + u) * 64);
+                const u32x4 x0 = row_ok ? px[0] : (u32x4){0u, 0u, 0u, 0u};
+                const u32x4 x1 = row_ok ? px[1] : (u32x4){0u, 0u, 0u, 0u};
+                u32x4 a0 = qa[u][0], a1 = qa[u][1], b0 = qb[u][0], b1 = qb[u][1];
+                if (FP8) {
+                    widen_fp8(qa[u][0], a0, a1);
+                    if (SWIGLU) widen_fp8(qb[u][0], b0, b1);
+                }
+                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a0), as_bf16x8(x0), acc_a, 0, 0, 0);
+                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a1), as_bf16x8(x1), acc_a, 0, 0, 0);
+                if (SWIGLU) {
+                    acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b0), as_bf16x8(x0), acc_b, 0, 0, 0);
+                    acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b1), as_bf16x8(x1), acc_b, 0, 0, 0);
+                }
+                refill(u);                          // this slot's next step, U ahead (the next group's once this one is issued out)
+            }
+        }
+        // ---- the eight K-slices meet in LDS; wave 0 sums them (slice order 0..7) and finishes the group ----
+        *(f32x4*)(red + ((size_t)(wave * 2 + 0) * 64 + lane) * 4) = acc_a;
+        if (SWIGLU) *(f32x4*)(red + ((size_t)(wave * 2 + 1) * 64 + lane) * 4) = acc_b;
+        __syncthreads();
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                sa += *(const f32x4*)(red + ((size_t)(w * 2 + 0) * 64 + lane) * 4);
+                if (SWIGLU) sb += *(const f32x4*)(red + ((size_t)(w * 2 + 1) * 64 + lane) * 4);
+            }
+        }
+        __syncthreads();                            // red is free for the next group; wave 0 finishes from registers
+        if (wave == 0 && row_ok) {
+            const int grp = blockIdx.x + j * gridDim.x;
+            const int m = fr;
+            const int n0 = grp * 16 + g * 4;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int n = n0 + jj;
+                if (n >= n_out_total) break;
+                float t;
+                if (SWIGLU) {
+                    float gt = sa[jj], up = sb[jj];
+                    if (FP8) { gt *= p.wscale[grp * 32 + g * 4 + jj]; up *= p.wscale[grp * 32 + 16 + g * 4 + jj]; }
+                    t = act_silu(gt) * up;
+                } else {
+                    t = sa[jj];
+                    if (FP8) t *= p.wscale[n];
+                    if (p.bias) t += p.bias[n];
+                    t = apply_act(t, p.act);
+                }
+                if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + n]);
+                if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + n] = t;
+                else ((bf16_t*)p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(t);
+            }
+        }
+    }
+}
+
+size_t skinny_persist_lds(const LinearArgs& a) { return (size_t)a.M * (a.K + 8) * 2 + (size_t)8 * 2 * 64 * 4 * sizeof(float); }
+
+bool skinny_persist_ok(const LinearArgs& a) {
+    if (!a.norm_w) return false;
+    const int steps = a.K >> 6, U = a.act == VZ_ACT_SWIGLU ? 4 : 8;
+    return steps % 8 == 0 && (steps / 8) % U == 0 && skinny_persist_lds(a) <= 160 * 1024;
+}
+
+int g_num_cu_skinny = 0;
+
+template <bool SWIGLU, bool FP8>
+int launch_persist(const SkinnyParams& p, int n_groups, size_t lds, hipStream_t s) {
+    const int per_cu = (160 * 1024) / (int)lds >= 2 ? 2 : 1;
+    const int cap = g_num_cu_skinny * per_cu;
+    const int grid = n_groups < cap ? n_groups : cap;
+    vz_launch_timed(skinny_persist_kernel<SWIGLU, FP8>, dim3(grid), dim3(512), lds, s, p, n_groups);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
 size_t skinny_lds(const LinearArgs& a) {
     return (a.norm_w ? (size_t)a.M * (a.K + 8) * 2 : 0) + (size_t)8 * 2 * 64 * 4 * sizeof(float);
 }
@@ -233,12 +389,15 @@ int launch(const SkinnyParams& p, int blocks, size_t lds, hipStream_t s) {
 
 int g_skinny_mode = 1;   // vz_tune_set(9, v): 1 = 2..16-row linears use the MFMA weight stream (default), 0 = GEMV / tile GEMM as before
 
+// 5..16 rows with the RMSNorm fused: only the persistent form holds the normalised rows in LDS at one workgroup per CU
+bool vz_skinny_fused_norm_ok(const LinearArgs& a) { return g_skinny_mode != 2 && a.M >= 2 && a.M <= 16 && skinny_persist_ok(a); }
+
 bool vz_skinny_ok(const LinearArgs& a) {
     if (a.M < 2 || a.M > 16 || (a.K & 63) != 0 || a.K < 512) return false;
     if (a.W8 && (!a.wscale || (a.ldw & 15) != 0 || ((uintptr_t)a.W8 & 15) != 0)) return false;
     if (a.act == VZ_ACT_SWIGLU && (a.N % 32) != 0) return false;
     if ((a.lda & 7) != 0 || (a.ldw & 7) != 0) return false;                       // 16-byte fragment loads
-    return skinny_lds(a) <= 160 * 1024;
+    return skinny_persist_ok(a) || skinny_lds(a) <= 160 * 1024;
 }
 
 int vz_init_skinny_kernels() {
@@ -251,6 +410,17 @@ int vz_init_skinny_kernels() {
     VZ_SK_ATTR(false, false, 4) VZ_SK_ATTR(false, false, 8) VZ_SK_ATTR(false, true, 4) VZ_SK_ATTR(false, true, 8)
     VZ_SK_ATTR(true, false, 4) VZ_SK_ATTR(true, false, 8) VZ_SK_ATTR(true, true, 4) VZ_SK_ATTR(true, true, 8)
 #undef VZ_SK_ATTR
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_persist_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_persist_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_persist_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_persist_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        VZ_CHECK_HIP(hipGetDevice(&dev));
+        VZ_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        g_num_cu_skinny = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     done = true;
     return VZ_OK;
 }
@@ -267,7 +437,13 @@ int vz_launch_skinny(const LinearArgs& a, hipStream_t s) {
     p.act = a.act; p.out_fp32 = a.out_fp32; p.norm_eps = a.norm_eps;
     const bool sw = a.act == VZ_ACT_SWIGLU;
     const int blocks = sw ? a.N / 32 : (a.N + 15) / 16;
+    if (g_skinny_mode != 2 && skinny_persist_ok(a) && (a.M > 4 || g_skinny_mode == 3)) {      // knob 9: 2 = never, 3 = also for 2..4 rows
+        const size_t pl = skinny_persist_lds(a);
+        if (p.W8) return sw ? launch_persist<true, true>(p, blocks, pl, s) : launch_persist<false, true>(p, blocks, pl, s);
+        return sw ? launch_persist<true, false>(p, blocks, pl, s) : launch_persist<false, false>(p, blocks, pl, s);
+    }
     const size_t lds = skinny_lds(a);
+    VZ_CHECK_ARG(lds <= 160 * 1024, "skinny gemm: %d activation rows of K=%d do not fit the LDS staging", a.M, a.K);
     if (sw) return a.norm_w ? launch<true, true>(p, blocks, lds, s) : launch<true, false>(p, blocks, lds, s);
     return a.norm_w ? launch<false, true>(p, blocks, lds, s) : launch<false, false>(p, blocks, lds, s);
 }

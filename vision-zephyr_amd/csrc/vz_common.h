@@ -129,6 +129,7 @@ bool vz_skinny_ok(const LinearArgs& a);      // 2..16 rows: MFMA weight stream (
 int vz_launch_skinny(const LinearArgs& a, hipStream_t s);
 int vz_init_skinny_kernels();
 extern int g_skinny_mode;
+bool vz_skinny_fused_norm_ok(const LinearArgs& a);
 int vz_init_gemv_kernels();
 void vz_set_gemv_variant(int v);
 // Profiling: when set, the next GEMM/GEMV launch is issued through hipExtLaunchKernelGGL with these events, which
