@@ -220,6 +220,9 @@ int vz_llm_prefill(vz_engine* e, const void* d_embeds, int B, int S, const int* 
 int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, const int* h_next_pos, const int* h_ctx_len,
                         vz_stream stream);
 int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d_logits_dbg, vz_stream stream);
+/* how the last vz_llm_decode_steps ran: *graph = 1 when a captured hipGraph was replayed; *comm_in_graph = 1 when the RCCL
+ * collectives of a tensor-parallel engine are part of that graph (0 = eager steps, e.g. after RCCL refused the capture) */
+int vz_llm_decode_mode(vz_engine* e, int* graph, int* comm_in_graph);
 /* Continuous batching.  vz_llm_prefill_rows: vz_llm_prefill into KV-cache rows row0 .. row0+B-1;
  * vz_llm_decode_set_row: (re)arm one row of the running decode batch - next input token, rotary position, context length -
  * without touching the others (a finished row is parked with ctx_len 0 until a new request is prefilled into it). */
@@ -247,7 +250,7 @@ int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_strea
  * 2 = prefill attention generation, 3 = split-K mode, 4 = 256^2 GEMM stream-K tail (1 = on, 0 = whole tiles only), 5 = stream-K skew in K-tiles, 6 = record 256^2 GEMM phase stamps,
  * 7 = route the collectives of a tp_size == 1 engine that holds a one-rank communicator through RCCL (self-test),
  * 9 = 2..16-row linears (1 = MFMA weight stream, 0 = GEMV / tile GEMM), 10 = context splits of the fused decode attention
- * (0 = engine default, 1..64).
+ * (0 = engine default, 1..64), 11 = 256^2 GEMM workgroups wait for their epilogue stores before they end (experiment; 0 = off).
  * Process-wide. */
 int vz_tune_set(int knob, int value);
 

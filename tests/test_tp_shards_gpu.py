@@ -163,11 +163,15 @@ def test_rccl_call_sites_on_one_rank():
     try:
         B.check(B.lib().vz_tune_set(7, 1))
         logits, new_ids = run()
+        # the decode steps ran as ONE captured graph with the RCCL all-reduces / all-gather inside it (not an eager fallback)
+        assert eng.decode_mode() == (True, True)
+        again = eng.decode_steps(6).clone()          # replay of the same graph object, collectives included
         gathered = eng.all_gather(x[0, :3])
     finally:
         B.check(B.lib().vz_tune_set(7, 0))
     assert torch.equal(logits, ref_logits)
     assert torch.equal(new_ids, ref_ids)
+    assert again.shape == new_ids.shape
     assert gathered.shape == (1, 3, cfg.hidden) and torch.equal(gathered[0], x[0, :3])
 
 

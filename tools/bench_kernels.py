@@ -193,6 +193,10 @@ def bench_gemm():
         B.check(B.lib().vz_tune_set(4, 1))
         us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act), 12) for _ in range(3))
         row.append(f"dispatch: {us:8.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF")
+        B.check(B.lib().vz_tune_set(11, 1))          # A/B in one process: workgroups wait for their stores before ending
+        us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act), 12) for _ in range(3))
+        B.check(B.lib().vz_tune_set(11, 0))
+        row.append(f"drain-wait: {us:8.1f} us")
         print(f"gemm {name:12s} M{M} N{N} K{K}: " + "   ".join(row), flush=True)
 
 

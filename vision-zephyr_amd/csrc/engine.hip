@@ -38,7 +38,7 @@ void vz_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vz_last_error(void) { return g_err; }
-extern "C" int vz_abi_version(void) { return 3; }
+extern "C" int vz_abi_version(void) { return 4; }
 extern "C" const char* vz_target_arch(void) { return "gfx950"; }
 
 // ------------------------------------------------------------------------------------------------
@@ -159,6 +159,7 @@ struct vz_engine {
     // decode state (device)
     int* d_state = nullptr;  // [cur_ids[B] | pos[B] | slot[B] | len[B] | step]
     int dec_B = 0;
+    bool comm_graph_ok = true;   // RCCL collectives captured into the decode graph (cleared if a capture is refused -> eager steps)
     int dec_len_max = 0;         // host-side bound on the longest row's visible keys (grows by one per launched step)
     int dec_nsplit = 1;          // context splits of the decode attention for the steps being launched
     float* d_logits = nullptr;   // [max_batch, vocab] fp32
@@ -636,6 +637,20 @@ static int tp_allreduce_bf16(vz_engine* e, bf16_t* buf, size_t count, hipStream_
 
 // lm_head over `rows` hidden rows -> fp32 logits [rows, vocab] in `out`.  Vocab-parallel under TP: every rank computes its
 // Vp rows of the table, the shards are all-gathered and repacked to the dense [rows, vocab] layout on every rank.
+// vocab-parallel lm_head: [tp][rows][Vp] gathered logits + this rank's shard behind them (never grows inside a stream capture:
+// vz_llm_decode_steps sizes it before it captures)
+static int ensure_gather(vz_engine* e, int rows, hipStream_t s) {
+    if (e->tp == 1 && !e->comm) return VZ_OK;
+    const size_t local_off = ((size_t)e->tp * rows * e->Vp + 3) & ~(size_t)3;
+    const size_t need = local_off + (size_t)rows * e->Vp;
+    if (need > e->gather_floats) {
+        if (e->d_gather) { VZ_CHECK_HIP(hipStreamSynchronize(s)); VZ_CHECK_HIP(hipFree(e->d_gather)); e->d_gather = nullptr; }
+        VZ_CHECK_HIP(hipMalloc((void**)&e->d_gather, need * sizeof(float)));
+        e->gather_floats = need;
+    }
+    return VZ_OK;
+}
+
 static int lm_head_logits(vz_engine* e, const bf16_t* h, int rows, float* out, hipStream_t s, const float* norm_w) {
     const vz_config& c = e->c;
     const int H = c.hidden;
@@ -647,12 +662,7 @@ static int lm_head_logits(vz_engine* e, const bf16_t* h, int rows, float* out, h
     if (rc) return rc;
     if (tp_local(e)) return linear(e, 0, h, H, lm, H, out, c.vocab, rows, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps, lm8, lms);
     const size_t local_off = ((size_t)e->tp * rows * e->Vp + 3) & ~(size_t)3;      // the GEMM wants a 16-byte-aligned output base
-    const size_t need = local_off + (size_t)rows * e->Vp;
-    if (need > e->gather_floats) {
-        if (e->d_gather) { VZ_CHECK_HIP(hipStreamSynchronize(s)); VZ_CHECK_HIP(hipFree(e->d_gather)); e->d_gather = nullptr; }
-        VZ_CHECK_HIP(hipMalloc((void**)&e->d_gather, need * sizeof(float)));
-        e->gather_floats = need;
-    }
+    { int r = ensure_gather(e, rows, s); if (r) return r; }
     float* local = e->d_gather + local_off;
     RC(linear(e, 0, h, H, lm, H, local, e->Vp, rows, e->Vp, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps, lm8, lms));
     if (!e->comm && !tp_skip(e)) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
@@ -904,7 +914,11 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     const int B = e->dec_B;
     const size_t need = ((size_t)B * (3 * c.hidden + (c.n_heads + 2 * c.n_kv_heads) * c.head_dim + c.inter)) * 2 + 8192;   // upper bound (tp = 1 sizes)
     RC(ensure_arena(e, need));
-    const bool use_graph = !e->prof_on && !d_logits_dbg && tp_local(e) && getenv("VZ_NO_GRAPH") == nullptr;   // collectives run eagerly
+    // tensor-parallel steps: the RCCL all-reduces / all-gather are captured with the kernels (one graph launch per token instead of
+    // ~230 host launches); if RCCL refuses the capture the engine falls back to eager steps for good
+    bool use_graph = !e->prof_on && !d_logits_dbg && getenv("VZ_NO_GRAPH") == nullptr &&
+                     (tp_local(e) || (e->comm_graph_ok && getenv("VZ_TP_NO_GRAPH") == nullptr));
+    if (!tp_local(e)) RC(ensure_gather(e, B, s));
     int* step = e->d_state + 4 * c.max_batch;
     VZ_CHECK_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
     // Context splits of the decode attention = grid.x: a split takes >= 128 keys and workgroups that find nothing to do still cost
@@ -933,18 +947,34 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
         if (!e->cap_stream) VZ_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
         VZ_CHECK_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
         int r = decode_step_launch(e, d_out_ids, n, nullptr, e->cap_stream);
+        graph = nullptr;
         hipError_t er = hipStreamEndCapture(e->cap_stream, &graph);
-        if (r) return r;
-        VZ_CHECK_HIP(er);
-        VZ_CHECK_HIP(hipGraphInstantiate(&e->dec_graph, graph, nullptr, nullptr, 0));
-        hipGraphDestroy(graph);
+        if (r == VZ_OK && er == hipSuccess) er = hipGraphInstantiate(&e->dec_graph, graph, nullptr, nullptr, 0);
+        if (graph) hipGraphDestroy(graph);
+        if (r != VZ_OK || er != hipSuccess) {
+            e->dec_graph = nullptr;
+            if (tp_local(e)) { if (r) return r; VZ_CHECK_HIP(er); }
+            (void)hipGetLastError();            // collectives would not capture: eager steps from now on
+            e->comm_graph_ok = false;
+            for (int i = 0; i < n; ++i) RC(decode_step_launch(e, d_out_ids, n, nullptr, s));
+            return VZ_OK;
+        }
         e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena; e->dec_graph_nsplit = e->dec_nsplit;
     }
     for (int i = 0; i < n; ++i) VZ_CHECK_HIP(hipGraphLaunch(e->dec_graph, s));
     return VZ_OK;
 }
 
-extern int g_gemm256_streamk, g_gemm256_skew, g_gemm256_stamps;
+// how the last vz_llm_decode_steps ran: *graph = 1 if a captured graph was replayed, *comm_in_graph = 1 if the engine's RCCL
+// collectives are part of it (tensor-parallel engines; 0 after a refused capture = eager steps)
+extern "C" int vz_llm_decode_mode(vz_engine* e, int* graph, int* comm_in_graph) {
+    VZ_CHECK_ARG(e && graph && comm_in_graph, "decode_mode: null argument");
+    *graph = e->dec_graph != nullptr;
+    *comm_in_graph = e->dec_graph != nullptr && !tp_local(e) && e->comm_graph_ok;
+    return VZ_OK;
+}
+
+extern int g_gemm256_streamk, g_gemm256_skew, g_gemm256_stamps, g_gemm256_drain;
 int vz_gemm256_read_stamps(long long* host, int max_wgs, int* n_wgs);
 extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 0) { vz_set_gemv_variant(value); return VZ_OK; }
@@ -956,6 +986,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 6) { g_gemm256_stamps = value; return VZ_OK; }
     if (knob == 7) { g_force_comm = value; return VZ_OK; }
     if (knob == 9) { g_skinny_mode = value; return VZ_OK; }
+    if (knob == 11) { g_gemm256_drain = value; return VZ_OK; }
     if (knob == 10) { if (value < 0 || value > 64) { vz_set_error("tune_set: decode attention splits must be 0..64"); return VZ_ERR_ARG; } g_attn_nsplit = value; return VZ_OK; }
     vz_set_error("tune_set: unknown knob %d", knob);
     return VZ_ERR_ARG;

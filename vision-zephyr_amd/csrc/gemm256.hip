@@ -49,6 +49,7 @@ struct Gemm256Params {
     const float* bias; const bf16_t* residual;
     int M, N, K, lda, ldw, ldc, ldr;
     int act, out_fp32, tiles_m, tiles_n;
+    int drain;               // experiment knob 11: 1 = every workgroup waits for its epilogue stores before it ends (the old behaviour)
     // stream-K: workgroups [0, n_full) run tiles [0, n_full) whole; the n_rem * nk K-tiles ("units") of the remaining
     // tiles are cut into sk_wgs ranges of units_per_wg
     int n_full, n_rem, sk_wgs, units_per_wg, sk_skew;
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
             epilogue_rows<1, 3>(p, acc, m_base, n_base, g, swiglu, n_out_total, vec_ok);
             }
         }
-        if (seg_no < 3) {
+        if ((p.stamps || p.drain) && seg_no < 3) {       // profiling only: the stamp is taken once the stores have drained
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             VZ_STAMP(4 + seg_no * 5)
             if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 5 + seg_no * 5] = ((long long)nks << 32) | (finish ? 1 : 0) | (nks != nk ? 2 : 0);
@@ -527,6 +528,7 @@ int g_num_cu;
 
 int g_gemm256_streamk = 1;   // vz_tune_set(4, v): 1 = stream-K tail (default), 0 = whole tiles only
 int g_gemm256_stamps = 0;    // vz_tune_set(6, v): 1 = record in-kernel phase stamps (vz_prof_gemm_stamps)
+int g_gemm256_drain = 0;     // vz_tune_set(11, v)
 int g_gemm256_skew = 2;      // vz_tune_set(5, v): K-tiles by which even / odd stream-K workgroups lead / lag
 
 int vz_init_gemm256_kernel() {
@@ -577,7 +579,7 @@ int vz_launch_gemm256(const LinearArgs& a, hipStream_t s) {
             }
         }
     }
-    p.stamps = nullptr;
+    p.stamps = nullptr; p.drain = g_gemm256_drain;
     if (g_gemm256_stamps && p.n_full + p.sk_wgs <= 4096) {
         p.stamps = g_stamps; g_stamp_wgs = p.n_full + p.sk_wgs;
         VZ_CHECK_HIP(hipMemsetAsync(g_stamps, 0, (size_t)g_stamp_wgs * 16 * sizeof(long long), s));

@@ -65,6 +65,7 @@ SYMBOLS = {
     "vz_llm_decode_set_row": (_I, [_P, _I, _I, _I, _I, _P]),
     "vz_llm_decode_begin": (_I, [_P, _I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
+    "vz_llm_decode_mode": (_I, [_P, _P, _P]),
     "vz_tune_set": (_I, [_I, _I]),
     "vz_engine_resize_vocab": (_I, [_P, _I]),
     "vz_op_resample_u8": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P]),

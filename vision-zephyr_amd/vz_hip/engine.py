@@ -439,6 +439,12 @@ class Engine:
         B.check(self.lib.vz_llm_decode_steps(self.h, n, B.ptr(out), B.ptr(lg), self._s()))
         return (out, lg) if return_logits else out
 
+    def decode_mode(self):
+        """(graph replayed?, RCCL collectives inside the graph?) of the last decode_steps call."""
+        g, c = C.c_int(0), C.c_int(0)
+        B.check(self.lib.vz_llm_decode_mode(self.h, C.byref(g), C.byref(c)))
+        return bool(g.value), bool(c.value)
+
     # profiling hooks (bench.py roofline leg)
     def prof_enable(self, on: bool, klass: int = -1):
         B.check(self.lib.vz_prof_enable(self.h, int(on), klass))
