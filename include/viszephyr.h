@@ -223,6 +223,10 @@ int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d_logits_dbg
 /* how the last vz_llm_decode_steps ran: *graph = 1 when a captured hipGraph was replayed; *comm_in_graph = 1 when the RCCL
  * collectives of a tensor-parallel engine are part of that graph (0 = eager steps, e.g. after RCCL refused the capture) */
 int vz_llm_decode_mode(vz_engine* e, int* graph, int* comm_in_graph);
+/* batch-1 decode runs QKV GEMV + attention + O GEMV of a layer as ONE launch whose roles hand over through device-side counters;
+ * every device-side wait is bounded and raises a word when it expires.  Reads and clears that word (blocking): *err != 0 = the
+ * outputs since the previous call are invalid. */
+int vz_engine_async_error(vz_engine* e, int* err);
 /* Continuous batching.  vz_llm_prefill_rows: vz_llm_prefill into KV-cache rows row0 .. row0+B-1;
  * vz_llm_decode_set_row: (re)arm one row of the running decode batch - next input token, rotary position, context length -
  * without touching the others (a finished row is parked with ctx_len 0 until a new request is prefilled into it). */
@@ -250,7 +254,7 @@ int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_strea
  * 2 = prefill attention generation, 3 = split-K mode, 4 = 256^2 GEMM stream-K tail (1 = on, 0 = whole tiles only), 5 = stream-K skew in K-tiles, 6 = record 256^2 GEMM phase stamps,
  * 7 = route the collectives of a tp_size == 1 engine that holds a one-rank communicator through RCCL (self-test),
  * 9 = 2..16-row linears (1 = MFMA weight stream, 0 = GEMV / tile GEMM), 10 = context splits of the fused decode attention
- * (0 = engine default, 1..64), 11 = 256^2 GEMM workgroups wait for their epilogue stores before they end (experiment; 0 = off).
+ * (0 = engine default, 1..64), 13 = record role stamps of that launch, 12 = one launch for QKV GEMV + attention + O GEMV of a batch-1 decode layer (1 = on; default 0), 11 = 256^2 GEMM workgroups wait for their epilogue stores before they end (experiment; 0 = off).
  * Process-wide. */
 int vz_tune_set(int knob, int value);
 
@@ -263,6 +267,9 @@ int vz_prof_read(vz_engine* e, long* n_launches, double* total_ms);
 /* in-kernel phase stamps (s_memrealtime, 100 MHz) of the last 256^2 GEMM launched with vz_tune_set(6, 1):
  * 16 int64 per workgroup = {start, then per K-slice: loop begin, loop end, fix-up end, epilogue end, (nk<<32 | flags)} */
 int vz_prof_gemm_stamps(long long* host_out, int max_wgs, int* n_wgs);
+/* same for the one-launch attention half of the batch-1 decode layer (vz_tune_set(13, 1)): 4 stamps per workgroup -
+ * start | wait done | finished | left early - of the LAST stamped launch (tools/fused_stamps.py) */
+int vz_prof_attn_half_stamps(long long* host_out, int max_wgs, int* n_wgs);
 
 #ifdef __cplusplus
 }

@@ -431,6 +431,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         while remaining > 0:
             n = min(sync_every, remaining) if eos else remaining
             ids = eng.decode_steps(n)[0].tolist()
+            eng.check_async()                 # a bounded device-side hand-off wait that expired = invalid ids: fail loudly
             remaining -= n
             for t in ids:
                 out.append(int(t))

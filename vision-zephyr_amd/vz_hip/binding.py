@@ -66,6 +66,8 @@ SYMBOLS = {
     "vz_llm_decode_begin": (_I, [_P, _I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
     "vz_llm_decode_mode": (_I, [_P, _P, _P]),
+    "vz_engine_async_error": (_I, [_P, _P]),
+    "vz_prof_attn_half_stamps": (_I, [_P, _I, _P]),
     "vz_tune_set": (_I, [_I, _I]),
     "vz_engine_resize_vocab": (_I, [_P, _I]),
     "vz_op_resample_u8": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P]),

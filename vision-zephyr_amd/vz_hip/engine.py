@@ -439,6 +439,13 @@ class Engine:
         B.check(self.lib.vz_llm_decode_steps(self.h, n, B.ptr(out), B.ptr(lg), self._s()))
         return (out, lg) if return_logits else out
 
+    def check_async(self):
+        """raise if a bounded device-side wait of the fused decode launch expired since the last check (outputs invalid)."""
+        err = C.c_int(0)
+        B.check(self.lib.vz_engine_async_error(self.h, C.byref(err)))
+        if err.value:
+            raise RuntimeError("vz_hip: a device-side hand-off wait expired during decode (outputs invalid); set vz_tune_set(12, 0)")
+
     def decode_mode(self):
         """(graph replayed?, RCCL collectives inside the graph?) of the last decode_steps call."""
         g, c = C.c_int(0), C.c_int(0)
