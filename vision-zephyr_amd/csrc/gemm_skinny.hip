@@ -213,6 +213,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
 // consumed, possibly with the next group's first steps), so the reduction / epilogue of a group hides under the loads in flight.
 // Same k assignment, same per-wave K-slices and the same summation order over the eight slices as skinny_kernel: results are
 // bit-identical to it.  Needs K/64 divisible by 8 waves x U steps (hidden 4096: 64 steps = 8 x 8).
+// hipcc waits for ALL loads in flight at the head of every 8-step pass (the refill sits behind a branch, its waitcnt pass does not
+// count across the back edge): bursts of 8 steps.  Measured alternative - unconditional refills, `s_waitcnt vmcnt(14)` before
+// every slot, seven slots always in flight: gate-up 64.9 us instead of 58.8 at 16 rows.  The synchronised bursts of the eight
+// waves (whole 8 KiB rows requested together) serve the DRAM better than eight desynchronised streams; kept as is.
 template <bool SWIGLU, bool FP8>
 __global__ __launch_bounds__(512) void skinny_persist_kernel(SkinnyParams p, int n_groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
