@@ -19,6 +19,7 @@ from vz_hip.engine import Engine  # noqa: E402
 
 ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 layers = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+MODE = int(sys.argv[3]) if len(sys.argv) > 3 else 1       # 1 = QKV + attention + O in one launch, 2 = attention + O
 cfg = synth.ArchConfig(n_layers=layers, clip_layers=20)
 eng = Engine(cfg, max_ctx=ctx + 64, max_tiles=1, max_text=8)
 eng.load_synthetic(0)
@@ -26,10 +27,10 @@ ids = synth.synth_ids(ctx, cfg.vocab, image_pos=-1, seed=5)
 x = eng.embed_tokens(ids).unsqueeze(0)
 _, last = eng.prefill(x, [ctx])
 eng.decode_begin(last.argmax(-1).to(torch.int32), [ctx], [ctx])
-B.check(B.lib().vz_tune_set(12, 1))                    # the one-launch form is opt-in
+B.check(B.lib().vz_tune_set(12, MODE))                    # the one-launch form is opt-in
 eng.decode_steps(32)                                   # graph replays: clocks / caches in their steady state
 torch.cuda.synchronize()
-B.check(B.lib().vz_tune_set(12, 1))
+B.check(B.lib().vz_tune_set(12, MODE))
 B.check(B.lib().vz_tune_set(13, 1))
 os.environ["VZ_NO_GRAPH"] = "1"                        # stamped launches run eagerly (the stamp buffer is a launch argument)
 eng.decode_steps(4)
@@ -39,13 +40,15 @@ buf = (C.c_longlong * (4096 * 4))()
 n = C.c_int(0)
 B.check(B.lib().vz_prof_attn_half_stamps(buf, 4096, C.byref(n)))
 st = np.ctypeslib.as_array(buf).reshape(4096, 4)[: n.value].astype(np.int64)
-nA, nC = 6144 // 16, 4096 // 16
+nA, nC = (6144 // 16 if MODE == 1 else 0), 4096 // 16
 nB = n.value - nA - nC
 t0 = st[:, 0][st[:, 0] > 0].min()
 us = lambda a: (a - t0) / 100.0                        # noqa: E731
 print(f"ctx {ctx}: {n.value} workgroups = {nB} attention + {nA} QKV rows + {nC} O rows; launch span {us(st.max()):.1f} us")
 for name, lo, hi in (("attention", 0, nB), ("QKV rows", nB, nB + nA), ("O rows", nB + nA, n.value)):
     s = st[lo:hi]
+    if hi <= lo:
+        continue
     act = s[:, 0] > 0
     fin = s[:, 2] > 0
     line = f"  {name:10s}: start {us(s[act, 0]).min():6.1f} .. {us(s[act, 0]).max():6.1f}"

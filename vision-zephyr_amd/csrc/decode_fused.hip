@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 3) void decode_attn_half_kernel(FusedLayerPara
             // holds its requests back until the attention workgroup of ONE KV head (its index mod Hkv) has seen all of that head's
             // QKV rows - the QKV stream is through by then - instead of competing with it from t = 0 (measured: QKV rows done at
             // 18 us with the competition, 12 us without); the 33 MB then stream under the attention chain.
-            wait_flags(p.to + 32, lane == 0 ? blk % p.Hkv : -1, -1, epoch, p.err, 1);
+            if (p.nA > 0) wait_flags(p.to + 32, lane == 0 ? blk % p.Hkv : -1, -1, epoch, p.err, 1);
             gv.issue(p.Wo, p.Wo8, p.A, K, row0, lane);
         }
 
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 3) void decode_attn_half_kernel(FusedLayerPara
     if (k0 < k1) issue(k0, min(CH, k1 - k0));
 
     // ---- the new token's q / k / v rows of this KV head: 96 producer workgroups ----
-    {
+    if (p.nA > 0) {
         // producers of this KV head: 32 workgroups of q rows, 8 of k rows, 8 of v rows (16 rows each)
         const int qb = p.Hq * D / 16, kb16 = p.Hkv * D / 16;
         const int i0 = lane < 32 ? hk * (G * D / 16) + lane : -1;
@@ -507,7 +507,7 @@ int vz_launch_attn_half(const AttnHalfArgs& a, hipStream_t s) {
     p.cosT = a.cosT; p.sinT = a.sinT; p.pos = a.pos; p.slot = a.slot;
     p.H = a.H; p.QKV = a.QKV; p.A = a.A; p.Hq = a.Hq; p.Hkv = a.Hkv; p.max_ctx = a.max_ctx; p.nsplit = a.nsplit; p.window = a.window;
     p.scale = a.scale; p.tq = a.tq; p.to = a.to; p.step = a.step; p.err = a.err;
-    p.nB = a.nsplit * a.Hkv; p.nA = a.QKV / 16; p.nC = a.H / 16;
+    p.nB = a.nsplit * a.Hkv; p.nA = g_decode_fuse == 2 ? 0 : a.QKV / 16; p.nC = a.H / 16;      // mode 2: the QKV GEMV ran as its own launch
     // the waiting attention workgroups must leave room for their producers (see the header): otherwise the caller's three-kernel path
     VZ_CHECK_ARG(g_capacity[which] > 0 && p.nB + 64 <= g_capacity[which], "decode attention half: %d waiting workgroups do not fit %d resident slots",
                  p.nB, g_capacity[which]);

@@ -894,6 +894,8 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
             f.tq = e->d_fcount + (size_t)i * 1024; f.to = f.tq + 960; f.step = step; f.err = e->d_ferr;
             if (rc) return rc;
             if (Hkv <= 8 && D == 128 && e->fuse_ok && vz_attn_half_ok(f)) {
+                if (g_decode_fuse == 2)         // attention + O only: the QKV GEMV stays its own launch
+                    RC(linear(e, 0, x, H, f.Wqkv, H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, f.norm_w, c.rms_eps, f.Wqkv8, f.sqkv));
                 ProfScope ps(e, K_FUSED, s);
                 RC(vz_launch_attn_half(f, s));
                 fused = true;
