@@ -288,7 +288,7 @@ def main():
         for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
             env.pop(k)
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(min(args.steps, 2)), "--warmup", "1",
-               "--layers", str(args.layers), "--new-tokens", str(args.new_tokens), "--no-cpu-baseline"]
+               "--layers", str(args.layers), "--new-tokens", str(args.new_tokens), "--no-cpu-baseline", "--no-fp8-leg"]
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
             if rank == 0:
