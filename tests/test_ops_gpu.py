@@ -553,6 +553,34 @@ def test_skinny_gemm_fused_rmsnorm(B, M, act):
         check_close(f"gemv vs skinny fused norm M{M}", gv, out, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(17, 6144, 4096, 0), (32, 4096, 14336, 0), (32, 28672, 4096, 3), (25, 4000, 1024, 1), (32, 32001, 4096, 0)])
+def test_skinny_wide_rows(B, M, N, K, act):
+    """17..32 rows: the weight fragment meets two B operands (rows 0..15, 16..31).  Against the fp64 reference, rows 0..15
+    bit-identical to the 16-row kernel on the same rows where both run 8 waves per group, with bias + residual, ragged N, and
+    the e4m3 weight stream."""
+    x = _rand((M, K), 1.0, 301).bfloat16()
+    w = _rand((N, K), 0.03, 302).bfloat16()
+    n_out = N // 2 if act == 3 else N
+    bias = None if act == 3 else _rand((N,), 0.1, 303)
+    res = _rand((M, n_out), 0.5, 304).bfloat16()
+    out = B.linear(x, w, bias=bias, residual=res, act=act, out_fp32=True)
+    check_close(f"skinny wide M{M} N{N} K{K} act{act}", out, _ref_linear(x, w, bias, res, act), 1e-4, 1e-4)
+    groups = N // 32 if act == 3 else (N + 15) // 16
+    head = B.linear(x[:16].contiguous(), w, bias=bias, residual=res[:16].contiguous(), act=act, out_fp32=True)
+    if groups < 512 or (K >> 6) < 16:
+        assert torch.equal(out[:16], head), "rows 0..15 differ from the 16-row kernel"
+    else:
+        check_close("wide vs 16-row kernel (4-wave groups)", out[:16], head, 1e-5, 1e-5)
+    for rep in range(2):
+        assert torch.equal(B.linear(x, w, bias=bias, residual=res, act=act, out_fp32=True), out)
+    if K % 1024 == 0 and (act != 3 or N % 64 == 0):
+        from vz_hip import quant
+        w8, ws = quant.quantize_rows(w)
+        wq = quant.dequantize_rows(w8, ws).bfloat16()
+        o8 = B.linear_fp8(x, w8, ws, bias=bias, residual=res, act=act, out_fp32=True)
+        check_close(f"skinny wide fp8 M{M} N{N}", o8, B.linear(x, wq, bias=bias, residual=res, act=act, out_fp32=True), 1e-4, 1e-4)
+
+
 @pytest.mark.parametrize("M,N,act", [(5, 6144, 0), (16, 6144, 3), (16, 28672, 3), (9, 32001, 0), (12, 4000, 1), (16, 48, 0)])
 def test_skinny_persistent_fused_norm(B, M, N, act):
     """5..16 rows with the RMSNorm fused: ONE workgroup per CU stages the normalised rows in LDS once and walks its row groups

@@ -20,7 +20,7 @@ from vz_hip.preprocess import AnyresPreprocessor  # noqa: E402
 FP8 = "fp8" in sys.argv[1:]
 layers = next((int(a) for a in sys.argv[1:] if a.isdigit()), 32)
 PINS = [[336, 672], [672, 336], [336, 1008], [1008, 336], [672, 672]]
-N_NEW, L_PROMPT, MAXB = 128, 200, 16
+N_NEW, L_PROMPT, MAXB = 128, 200, 32
 
 from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM  # noqa: E402
 
@@ -38,7 +38,7 @@ rng = np.random.default_rng(0)
 frames = [torch.from_numpy(rng.integers(0, 256, (804, 1920, 3), dtype=np.uint8)) for _ in range(MAXB)]     # host memory, as a loader hands them over
 prompts = [synth.synth_ids(L_PROMPT, 32000, image_pos=5, seed=100 + i) for i in range(MAXB)]
 
-for B in (1, 4, 8, 16):
+for B in (1, 4, 8, 16, 32):
     def run():
         t0 = time.perf_counter()
         tiles = [pre(f, PINS) for f in frames[:B]]                          # H2D + LANCZOS + tiling + normalise on the device

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel trace of tools/bench_batched.py, summarised per kernel over the 16-row decode steps (the trace itself is not kept)
+# rocprofv3 kernel trace of tools/bench_batched.py, summarised per kernel over the widest batch's decode steps (the trace itself is not kept)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d /tmp/prof_bb -o bb --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/bench_batched.py "$@" > /tmp/bb.log 2>&1
 grep batch /tmp/bb.log
