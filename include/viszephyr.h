@@ -74,7 +74,7 @@ int vz_op_linear_fp8(const void* d_A, int lda, const void* d_W8, int ldw, const 
 int vz_op_linear_rmsnorm(const void* d_A, int lda, const float* d_norm_w, float norm_eps, const void* d_W, int ldw, void* d_C, int ldc,
                          int M, int N, int K, const void* d_residual, int ldr, int act, int out_fp32, vz_stream stream);
 /* same contract, forcing one implementation (tests): impl 0 = 128^2 MFMA tile GEMM, 1 = GEMV (M <= 8), 2 = 256^2 tile GEMM,
- * 3 = MFMA weight stream for 2 <= M <= 16 (batched decode) */
+ * 3 = MFMA weight stream for 2 <= M <= 64 (batched decode) */
 int vz_op_linear_impl(int impl, const void* d_A, int lda, const void* d_W, int ldw, void* d_C, int ldc,
                       int M, int N, int K, const float* d_bias, const void* d_residual, int ldr,
                       int act, int out_fp32, vz_stream stream);

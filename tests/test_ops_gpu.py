@@ -553,9 +553,10 @@ def test_skinny_gemm_fused_rmsnorm(B, M, act):
         check_close(f"gemv vs skinny fused norm M{M}", gv, out, 1e-4, 1e-4)
 
 
-@pytest.mark.parametrize("M,N,K,act", [(17, 6144, 4096, 0), (32, 4096, 14336, 0), (32, 28672, 4096, 3), (25, 4000, 1024, 1), (32, 32001, 4096, 0)])
+@pytest.mark.parametrize("M,N,K,act", [(17, 6144, 4096, 0), (32, 4096, 14336, 0), (32, 28672, 4096, 3), (25, 4000, 1024, 1), (32, 32001, 4096, 0),
+                                       (33, 6144, 4096, 0), (64, 4096, 14336, 0), (64, 28672, 4096, 3), (50, 4000, 1024, 2), (64, 32001, 4096, 0)])
 def test_skinny_wide_rows(B, M, N, K, act):
-    """17..32 rows: the weight fragment meets two B operands (rows 0..15, 16..31).  Against the fp64 reference, rows 0..15
+    """17..64 rows: the weight fragment meets two / four B operands (rows 16h .. 16h+15).  Against the fp64 reference, rows 0..15
     bit-identical to the 16-row kernel on the same rows where both run 8 waves per group, with bias + residual, ragged N, and
     the e4m3 weight stream."""
     x = _rand((M, K), 1.0, 301).bfloat16()

@@ -516,9 +516,9 @@ def test_fp8_weight_engine_matches_quantized_oracle(env):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("Bn", [5, 16, 19, 32])
+@pytest.mark.parametrize("Bn", [5, 16, 19, 32, 41, 64])
 def test_wide_batch_decode_matches_prefill(env, Bn):
-    """5..32 rows decode through the MFMA weight stream (gemm_skinny.hip; 17..32 rows: two B operands per weight fragment, the
+    """5..64 rows decode through the MFMA weight stream (gemm_skinny.hip; 17..64 rows: two / four B operands per weight fragment, the
     RMSNorm once into an L2-resident scratch):
     under teacher forcing every row's decode-step logits must equal its prefill logits at the same position (KV slots,
     per-row positions / lengths, ragged prompts), and batched greedy generation must give each row what it gets alone."""
@@ -531,7 +531,7 @@ def test_wide_batch_decode_matches_prefill(env, Bn):
     hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
     hf.mm_patch_merge_type = "flat"
     hf.mm_hidden_size = 5120
-    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=32, max_ctx=128, max_tiles=1, max_text=16)
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=64, max_ctx=128, max_tiles=1, max_text=16)
     eng = model.engine
     lens = [20 + (7 * b) % 13 for b in range(Bn)]
     Smax = max(lens) + 1

@@ -32,9 +32,9 @@ def build(max_batch):
                                                weight_fp8=FP8)
 
 
-model = build(32)
+model = build(64)
 n_new = 64
-for B in (1, 2, 4, 8, 16, 24, 32):
+for B in (1, 2, 4, 8, 16, 32, 48, 64):
     ids = torch.stack([synth.synth_ids(64, 32000, image_pos=-1, seed=10 + b) for b in range(B)]).cuda()
     model.generate(input_ids=ids, do_sample=False, max_new_tokens=n_new, eos_token_id=None, pad_token_id=2)
     torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """SURVEY config 5 in miniature (one GPU): VCR-style items - a 1920 x 804 frame (anyres -> 4 tiles) + a ~200-token prompt, 128 new
 tokens - through device preprocessing -> CLIP / fusion / Q-Former -> batched greedy generation.  Prints items/s and decode
-tokens/s for batch sizes 1..16 (bf16 weights, or `fp8` for the W8A16 engine).
+tokens/s for batch sizes 1..64 (bf16 weights, or `fp8` for the W8A16 engine).
 
     python tools/bench_vcr.py [fp8] [layers]"""
 import os
@@ -20,7 +20,7 @@ from vz_hip.preprocess import AnyresPreprocessor  # noqa: E402
 FP8 = "fp8" in sys.argv[1:]
 layers = next((int(a) for a in sys.argv[1:] if a.isdigit()), 32)
 PINS = [[336, 672], [672, 336], [336, 1008], [1008, 336], [672, 672]]
-N_NEW, L_PROMPT, MAXB = 128, 200, 32
+N_NEW, L_PROMPT, MAXB = 128, 200, 64
 
 from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM  # noqa: E402
 
@@ -38,7 +38,7 @@ rng = np.random.default_rng(0)
 frames = [torch.from_numpy(rng.integers(0, 256, (804, 1920, 3), dtype=np.uint8)) for _ in range(MAXB)]     # host memory, as a loader hands them over
 prompts = [synth.synth_ids(L_PROMPT, 32000, image_pos=5, seed=100 + i) for i in range(MAXB)]
 
-for B in (1, 4, 8, 16, 32):
+for B in (1, 4, 8, 16, 32, 64):
     def run():
         t0 = time.perf_counter()
         tiles = [pre(f, PINS) for f in frames[:B]]                          # H2D + LANCZOS + tiling + normalise on the device

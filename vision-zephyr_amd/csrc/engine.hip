@@ -164,7 +164,7 @@ struct vz_engine {
     int dec_len_max = 0;         // host-side bound on the longest row's visible keys (grows by one per launched step)
     int dec_nsplit = 1;          // context splits of the decode attention for the steps being launched
     float* d_logits = nullptr;   // [max_batch, vocab] fp32
-    bf16_t* d_xnorm = nullptr;   // [32, hidden]: normalised rows of a 5..16-row decode batch (the MFMA weight stream reads them from L2)
+    bf16_t* d_xnorm = nullptr;   // [64, hidden]: normalised rows of a 5..16-row decode batch (the MFMA weight stream reads them from L2)
     float* d_part = nullptr;     // decode attention partials
     unsigned* d_ticket = nullptr; // arrival counters of the fused decode attention
     unsigned* d_fcount = nullptr; // [n_layers][1024] hand-off flags of the one-launch attention half (decode_fused.hip)
@@ -238,7 +238,7 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
         if (M > 16) t.norm_w = nullptr;   // 17..32 rows: the norm runs as its own kernel below
         if (!vz_gemv_ok(t) && !(g_skinny_mode && vz_skinny_ok(t))) { a.W8 = nullptr; a.wscale = nullptr; }
     }
-    if (norm_w && M > 4 && M <= 32 && K == e->c.hidden && g_skinny_mode && !(vz_skinny_ok(a) && vz_skinny_fused_norm_ok(a))) {
+    if (norm_w && M > 4 && M <= 64 && K == e->c.hidden && g_skinny_mode && !(vz_skinny_ok(a) && vz_skinny_fused_norm_ok(a))) {
         // 5..16 rows without the persistent fused-norm kernel (knob 9 = 2, or a K it does not take): normalise once into an
         // L2-resident scratch and let the one-group-per-workgroup MFMA weight stream take its B fragments from there
         { ProfScope ps(e, K_NORM, s); int r = vz_launch_rmsnorm(A, lda, e->d_xnorm, K, norm_w, M, K, norm_eps, s); if (r) return r; }
@@ -318,7 +318,7 @@ extern "C" int vz_engine_create(const vz_config* cfg, vz_engine** out) {
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_logits, (size_t)c.max_batch * e->Vp * e->tp * sizeof(float));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_part, (size_t)c.max_batch * e->Hkv_l * 64 * (4 * 128 + 32) * sizeof(float));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_ticket, 4096);
-    if (er == hipSuccess) er = hipMalloc((void**)&e->d_xnorm, (size_t)32 * c.hidden * sizeof(bf16_t));
+    if (er == hipSuccess) er = hipMalloc((void**)&e->d_xnorm, (size_t)64 * c.hidden * sizeof(bf16_t));
     if (er == hipSuccess) er = hipMemset(e->d_ticket, 0, 4096);
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_fcount, (size_t)c.n_layers * 1024 * sizeof(unsigned));
     if (er == hipSuccess) er = hipMemset(e->d_fcount, 0, (size_t)c.n_layers * 1024 * sizeof(unsigned));
@@ -827,7 +827,7 @@ extern "C" int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, 
     NEED_READY();
     const vz_config& c = e->c;
     hipStream_t s = (hipStream_t)stream;
-    VZ_CHECK_ARG(B >= 1 && B <= c.max_batch && B <= 32 && d_first_ids && h_next_pos && h_ctx_len, "decode_begin: B=%d unsupported (1..min(32,max_batch))", B);
+    VZ_CHECK_ARG(B >= 1 && B <= c.max_batch && B <= 64 && d_first_ids && h_next_pos && h_ctx_len, "decode_begin: B=%d unsupported (1..min(64,max_batch))", B);
     const int mb = c.max_batch;
     std::vector<int> h(3 * mb + 4, 0);
     for (int b = 0; b < B; ++b) {

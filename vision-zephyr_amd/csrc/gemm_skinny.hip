@@ -206,18 +206,18 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     }
 }
 
-// 17..32 activation rows: the same weight stream with TWO B operands per weight fragment (rows 0..15 and 16..31) - one pass over
-// the weights for up to 32 sequences.  Activations come straight from global / L2 (already normalised by the caller: 32 rows x
-// 8 KiB do not fit LDS next to a second workgroup), 4 steps in flight.  Same k assignment and slice order as skinny_kernel.
-template <bool SWIGLU, int NW, bool FP8 = false>
+// 17..64 activation rows: the same weight stream with MH = 2 or 4 B operands per weight fragment (rows 16h .. 16h+15) - one pass
+// over the weights for up to 64 sequences.  Activations come straight from global / L2 (already normalised by the caller: 32+ rows x
+// 8 KiB do not fit LDS next to a second workgroup); 4 steps in flight (2 with four operands).  Same k assignment and slice
+// order as skinny_kernel.
+template <bool SWIGLU, int NW, bool FP8, int MH>
 __global__ __launch_bounds__(NW * 64) void skinny_wide_kernel(SkinnyParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int K = p.K;
-    float* red = (float*)smem;                                             // [NW][4][64][4]
+    float* red = (float*)smem;                                             // [NW][2 MH][64][4]
 
-    // ---- weight rows of this workgroup ----
     const int grp = blockIdx.x;
     int row_a, row_b = 0;                                                  // row this lane streams (tile a; SwiGLU: tile b = up)
     if (SWIGLU) { row_a = grp * 32 + fr; row_b = row_a + 16; }
@@ -227,17 +227,20 @@ __global__ __launch_bounds__(NW * 64) void skinny_wide_kernel(SkinnyParams p) {
     const unsigned char* wa8 = p.W8 + (size_t)row_a * p.ldw + g * 16;      // FP8: 16 bytes = the same 16 k of a step
     const unsigned char* wb8 = p.W8 + (size_t)row_b * p.ldw + g * 16;
 
-    // ---- this wave's K-slice, in steps of 64 k ----
-    constexpr int U = 4;
+    constexpr int U = MH == 2 ? 4 : 2;
     const int steps = K >> 6;
     const int per = (steps + NW - 1) / NW;
     const int s0 = wave * per < steps ? wave * per : steps;
     const int s1 = s0 + per < steps ? s0 + per : steps;
 
-    u32x4 qa[U][2], qb[U][2], qx[U][2], qy[U][2];
-    const bool row_ok = fr < p.M, row2_ok = fr + 16 < p.M;
-    const bf16_t* xg = p.A + (size_t)(row_ok ? fr : 0) * p.lda + g * 16;            // rows 0..15
-    const bf16_t* yg = p.A + (size_t)(row2_ok ? fr + 16 : 0) * p.lda + g * 16;      // rows 16..31
+    u32x4 qa[U][2], qb[U][2], qx[MH][U][2];
+    bool ok[MH];
+    const bf16_t* xg[MH];
+#pragma unroll
+    for (int h = 0; h < MH; ++h) {
+        ok[h] = fr + 16 * h < p.M;
+        xg[h] = p.A + (size_t)(ok[h] ? fr + 16 * h : 0) * p.lda + g * 16;
+    }
     auto issue = [&](int i0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -248,68 +251,65 @@ __global__ __launch_bounds__(NW * 64) void skinny_wide_kernel(SkinnyParams p) {
                     if (SWIGLU) qb[u][0] = *(const u32x4*)(wb8 + (size_t)s * 64);
                 } else {
                     const u32x4* pa = (const u32x4*)(wa + (size_t)s * 64);
-                    qa[u][0] = pa[0]; qa[u][1] = pa[1];        // default cache policy: the two halves of a line are requested by two instructions
+                    qa[u][0] = pa[0]; qa[u][1] = pa[1];
                     if (SWIGLU) {
                         const u32x4* pb = (const u32x4*)(wb + (size_t)s * 64);
                         qb[u][0] = pb[0]; qb[u][1] = pb[1];
                     }
                 }
-                {
-                    const u32x4* px = (const u32x4*)(xg + (size_t)s * 64);
-                    qx[u][0] = row_ok ? px[0] : (u32x4){0u, 0u, 0u, 0u};
-                    qx[u][1] = row_ok ? px[1] : (u32x4){0u, 0u, 0u, 0u};
-                    const u32x4* py = (const u32x4*)(yg + (size_t)s * 64);
-                    qy[u][0] = row2_ok ? py[0] : (u32x4){0u, 0u, 0u, 0u};
-                    qy[u][1] = row2_ok ? py[1] : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int h = 0; h < MH; ++h) {
+                    const u32x4* px = (const u32x4*)(xg[h] + (size_t)s * 64);
+                    qx[h][u][0] = ok[h] ? px[0] : (u32x4){0u, 0u, 0u, 0u};
+                    qx[h][u][1] = ok[h] ? px[1] : (u32x4){0u, 0u, 0u, 0u};
                 }
             }
         }
     };
-    issue(s0);          // the first weights are in flight before the norm prologue
+    issue(s0);
 
-    f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f}, acc_a2 = {0.f, 0.f, 0.f, 0.f}, acc_b2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc_a[MH], acc_b[MH];
+#pragma unroll
+    for (int h = 0; h < MH; ++h) { acc_a[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc_b[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     for (int i0 = s0; i0 < s1; i0 += U) {
         if (i0 != s0) issue(i0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int s = i0 + u;
             if (s < s1) {
-                const u32x4 x0 = qx[u][0], x1 = qx[u][1], y0 = qy[u][0], y1 = qy[u][1];
                 u32x4 a0 = qa[u][0], a1 = qa[u][1], b0 = qb[u][0], b1 = qb[u][1];
                 if (FP8) {
                     widen_fp8(qa[u][0], a0, a1);
                     if (SWIGLU) widen_fp8(qb[u][0], b0, b1);
                 }
-                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a0), as_bf16x8(x0), acc_a, 0, 0, 0);
-                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a1), as_bf16x8(x1), acc_a, 0, 0, 0);
-                acc_a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a0), as_bf16x8(y0), acc_a2, 0, 0, 0);
-                acc_a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a1), as_bf16x8(y1), acc_a2, 0, 0, 0);
-                if (SWIGLU) {
-                    acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b0), as_bf16x8(x0), acc_b, 0, 0, 0);
-                    acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b1), as_bf16x8(x1), acc_b, 0, 0, 0);
-                    acc_b2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b0), as_bf16x8(y0), acc_b2, 0, 0, 0);
-                    acc_b2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b1), as_bf16x8(y1), acc_b2, 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < MH; ++h) {
+                    acc_a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a0), as_bf16x8(qx[h][u][0]), acc_a[h], 0, 0, 0);
+                    acc_a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a1), as_bf16x8(qx[h][u][1]), acc_a[h], 0, 0, 0);
+                    if (SWIGLU) {
+                        acc_b[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b0), as_bf16x8(qx[h][u][0]), acc_b[h], 0, 0, 0);
+                        acc_b[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b1), as_bf16x8(qx[h][u][1]), acc_b[h], 0, 0, 0);
+                    }
                 }
             }
         }
     }
 
-    // ---- the K-slices meet in LDS ([NW][4 tiles][64][4]); waves 0 and 1 finish rows 0..15 and 16..31 ----
-    *(f32x4*)(red + ((size_t)(wave * 4 + 0) * 64 + lane) * 4) = acc_a;
-    *(f32x4*)(red + ((size_t)(wave * 4 + 1) * 64 + lane) * 4) = acc_a2;
-    if (SWIGLU) {
-        *(f32x4*)(red + ((size_t)(wave * 4 + 2) * 64 + lane) * 4) = acc_b;
-        *(f32x4*)(red + ((size_t)(wave * 4 + 3) * 64 + lane) * 4) = acc_b2;
+    // ---- the K-slices meet in LDS ([NW][2 MH tiles][64][4]); wave h finishes rows 16h .. 16h+15 ----
+#pragma unroll
+    for (int h = 0; h < MH; ++h) {
+        *(f32x4*)(red + ((size_t)(wave * 2 * MH + h) * 64 + lane) * 4) = acc_a[h];
+        if (SWIGLU) *(f32x4*)(red + ((size_t)(wave * 2 * MH + MH + h) * 64 + lane) * 4) = acc_b[h];
     }
     __syncthreads();
-    if (wave > 1) return;
+    if (wave >= MH) return;
     const int m = fr + 16 * wave;
     if (m >= p.M) return;
     f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-        sa += *(const f32x4*)(red + ((size_t)(w * 4 + wave) * 64 + lane) * 4);
-        if (SWIGLU) sb += *(const f32x4*)(red + ((size_t)(w * 4 + 2 + wave) * 64 + lane) * 4);
+        sa += *(const f32x4*)(red + ((size_t)(w * 2 * MH + wave) * 64 + lane) * 4);
+        if (SWIGLU) sb += *(const f32x4*)(red + ((size_t)(w * 2 * MH + MH + wave) * 64 + lane) * 4);
     }
     const int n_out_total = SWIGLU ? p.N / 2 : p.N;
     const int n0 = grp * 16 + g * 4;
@@ -525,8 +525,8 @@ int g_skinny_mode = 1;   // vz_tune_set(9, v): 1 = 2..16-row linears use the MFM
 bool vz_skinny_fused_norm_ok(const LinearArgs& a) { return g_skinny_mode != 2 && a.M >= 2 && a.M <= 16 && skinny_persist_ok(a); }
 
 bool vz_skinny_ok(const LinearArgs& a) {
-    if (a.M < 2 || a.M > 32 || (a.K & 63) != 0 || a.K < 512) return false;
-    if (a.M > 16 && a.norm_w) return false;                                       // 17..32 rows: the caller normalises (no LDS staging)
+    if (a.M < 2 || a.M > 64 || (a.K & 63) != 0 || a.K < 512) return false;
+    if (a.M > 16 && a.norm_w) return false;                                       // 17..64 rows: the caller normalises (no LDS staging)
     if (a.W8 && (!a.wscale || (a.ldw & 15) != 0 || ((uintptr_t)a.W8 & 15) != 0)) return false;
     if (a.act == VZ_ACT_SWIGLU && (a.N % 32) != 0) return false;
     if ((a.lda & 7) != 0 || (a.ldw & 7) != 0) return false;                       // 16-byte fragment loads
@@ -561,7 +561,7 @@ int vz_init_skinny_kernels() {
 int vz_launch_skinny(const LinearArgs& a, hipStream_t s) {
     int rc = vz_linear_check_common(a);
     if (rc) return rc;
-    VZ_CHECK_ARG(vz_skinny_ok(a), "skinny gemm: needs 2 <= M <= 32 (fused norm: <= 16), bf16 weights, K %% 64 == 0 and >= 512, 16-byte-aligned rows (M=%d K=%d)", a.M, a.K);
+    VZ_CHECK_ARG(vz_skinny_ok(a), "skinny gemm: needs 2 <= M <= 64 (fused norm: <= 16), bf16 weights, K %% 64 == 0 and >= 512, 16-byte-aligned rows (M=%d K=%d)", a.M, a.K);
     { int r = vz_init_skinny_kernels(); if (r) return r; }
     SkinnyParams p;
     p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.residual = a.residual; p.norm_w = a.norm_w;
@@ -570,14 +570,19 @@ int vz_launch_skinny(const LinearArgs& a, hipStream_t s) {
     p.act = a.act; p.out_fp32 = a.out_fp32; p.norm_eps = a.norm_eps;
     const bool sw = a.act == VZ_ACT_SWIGLU;
     const int blocks = sw ? a.N / 32 : (a.N + 15) / 16;
-    if (a.M > 16) {          // 17..32 rows: two B operands per weight fragment
-        const size_t wl = (size_t)8 * 4 * 64 * 4 * sizeof(float);
+    if (a.M > 16) {          // 17..64 rows: two / four B operands per weight fragment
         const bool four = blocks >= 512 && (p.K >> 6) >= 16;
-#define VZ_WIDE(SW, NWV, F8) do { vz_launch_timed(skinny_wide_kernel<SW, NWV, F8>, dim3(blocks), dim3(NWV * 64), wl, s, p); VZ_LAUNCH_CHECK(); return VZ_OK; } while (0)
-        if (p.W8) { if (sw) { if (four) VZ_WIDE(true, 4, true); VZ_WIDE(true, 8, true); } if (four) VZ_WIDE(false, 4, true); VZ_WIDE(false, 8, true); }
-        if (sw) { if (four) VZ_WIDE(true, 4, false); VZ_WIDE(true, 8, false); }
-        if (four) VZ_WIDE(false, 4, false);
-        VZ_WIDE(false, 8, false);
+#define VZ_WIDE(SW, NWV, F8, MHV) do { \
+            static bool attr = false; \
+            if (!attr) { VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_wide_kernel<SW, NWV, F8, MHV>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr = true; } \
+            vz_launch_timed(skinny_wide_kernel<SW, NWV, F8, MHV>, dim3(blocks), dim3(NWV * 64), (size_t)NWV * 2 * MHV * 64 * 4 * sizeof(float), s, p); \
+            VZ_LAUNCH_CHECK(); return VZ_OK; } while (0)
+#define VZ_WIDE_MH(SW, NWV, F8) do { if (a.M > 32) VZ_WIDE(SW, NWV, F8, 4); VZ_WIDE(SW, NWV, F8, 2); } while (0)
+        if (p.W8) { if (sw) { if (four) VZ_WIDE_MH(true, 4, true); VZ_WIDE_MH(true, 8, true); } if (four) VZ_WIDE_MH(false, 4, true); VZ_WIDE_MH(false, 8, true); }
+        if (sw) { if (four) VZ_WIDE_MH(true, 4, false); VZ_WIDE_MH(true, 8, false); }
+        if (four) VZ_WIDE_MH(false, 4, false);
+        VZ_WIDE_MH(false, 8, false);
+#undef VZ_WIDE_MH
 #undef VZ_WIDE
     }
     if (g_skinny_mode != 2 && skinny_persist_ok(a) && (a.M > 4 || g_skinny_mode == 3)) {      // knob 9: 2 = never, 3 = also for 2..4 rows

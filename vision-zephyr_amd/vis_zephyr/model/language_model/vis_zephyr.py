@@ -275,12 +275,12 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         return res
 
     def _generate_batched(self, embeds, seqlens, position_ids, max_new, eos, pad_token_id, sync_every, timing=None) -> torch.Tensor:
-        """Greedy decoding of up to `max_batch` (<= 32) sequences at once: one right-padded prefill, then every decode step
+        """Greedy decoding of up to `max_batch` (<= 64) sequences at once: one right-padded prefill, then every decode step
         streams the weights once for all rows (the KV cache, positions and lengths are per slot).  Rows that hit eos keep
         their slot but emit `pad_token_id` from then on, as HF does."""
         eng = self.engine
         Bsz, S = embeds.shape[0], embeds.shape[1]
-        cap = min(eng.max_batch, 32)
+        cap = min(eng.max_batch, 64)
         if Bsz > cap:
             parts = [self._generate_batched(embeds[i:i + cap], seqlens[i:i + cap],
                                             None if position_ids is None else position_ids[i:i + cap], max_new, eos,
@@ -337,9 +337,9 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         if eos_token_id is None:
             eos_token_id = self.generation_config.eos_token_id
         eos = set() if eos_token_id is None else ({int(eos_token_id)} if isinstance(eos_token_id, int) else {int(t) for t in eos_token_id})
-        n_rows = min(eng.max_batch, 32) if rows is None else int(rows)
-        if not 1 <= n_rows <= min(eng.max_batch, 32):
-            raise ValueError(f"rows must be in [1, {min(eng.max_batch, 32)}]")
+        n_rows = min(eng.max_batch, 64) if rows is None else int(rows)
+        if not 1 <= n_rows <= min(eng.max_batch, 64):
+            raise ValueError(f"rows must be in [1, {min(eng.max_batch, 64)}]")
         it = iter(enumerate(requests))
         slots = [None] * n_rows                 # per row: [request index, tokens so far, budget]
         eng.decode_begin(torch.zeros(n_rows, dtype=torch.int32), [0] * n_rows, [0] * n_rows)       # every row parked
