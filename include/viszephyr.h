@@ -63,7 +63,7 @@ const char* vz_target_arch(void);
 int vz_op_linear(const void* d_A, int lda, const void* d_W, int ldw, void* d_C, int ldc,
                  int M, int N, int K, const float* d_bias, const void* d_residual, int ldr,
                  int act, int out_fp32, vz_stream stream);
-/* W8A16 weight stream for M <= 8 (decode): W as OCP e4m3 rows [N, ldw bytes] + one fp32 power-of-two scale per row
+/* W8A16 weight stream for M <= 64 (decode batches; fused RMSNorm: M <= 16): W as OCP e4m3 rows [N, ldw bytes] + one fp32 power-of-two scale per row
  * (vz_hip/quant.py: 2^e * fp8 is exactly a bf16 number, so the bf16 GEMMs of the prefill run on the same weights).
  * Same epilogues as vz_op_linear; K % 1024 == 0; d_norm_w != NULL fuses the RMSNorm of x into the staging. */
 int vz_op_linear_fp8(const void* d_A, int lda, const void* d_W8, int ldw, const float* d_wscale, void* d_C, int ldc,

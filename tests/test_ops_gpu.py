@@ -506,7 +506,7 @@ def test_gemv_fp8_rejects_bad_arguments(B):
         B.linear_fp8(_rand((1, 1536), 1.0, 98).bfloat16(), w8, scale)        # K not a multiple of 1024
     w8, scale = quant.quantize_rows(_rand((64, 2048), 0.02, 97))
     with pytest.raises(ValueError):
-        B.linear_fp8(_rand((17, 2048), 1.0, 98).bfloat16(), w8, scale)       # M > 16: the fp8 stream serves decode batches only
+        B.linear_fp8(_rand((65, 2048), 1.0, 98).bfloat16(), w8, scale)       # M > 64: the fp8 stream serves decode batches only
 
 
 # ---- MFMA weight stream for 2..16 activation rows (batched decode; gemm_skinny.hip) ----

@@ -178,7 +178,7 @@ def linear_rmsnorm(x: torch.Tensor, norm_w: torch.Tensor, eps: float, w: torch.T
 
 def linear_fp8(x: torch.Tensor, w8: torch.Tensor, scale: torch.Tensor, bias=None, residual=None, act: int = ACT_NONE,
                out_fp32=False, norm_w=None, norm_eps: float = 0.0) -> torch.Tensor:
-    """W8A16 weight stream: epi(x[M<=8,K] @ (scale[:,None] * e4m3(w8))[N,K]^T); x bf16, w8 uint8 (e4m3 bytes), scale fp32 [N]."""
+    """W8A16 weight stream: epi(x[M<=64,K] @ (scale[:,None] * e4m3(w8))[N,K]^T); x bf16, w8 uint8 (e4m3 bytes), scale fp32 [N]."""
     _need_cuda(x, w8, scale, bias, residual, norm_w)
     assert x.dtype == torch.bfloat16 and w8.dtype == torch.uint8 and scale.dtype == torch.float32
     assert x.dim() == 2 and w8.dim() == 2 and x.stride(1) == 1 and w8.stride(1) == 1
