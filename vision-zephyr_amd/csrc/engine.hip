@@ -232,6 +232,7 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
                   const float* norm_w = nullptr, float norm_eps = 0.f, const unsigned char* W8 = nullptr, const float* ws = nullptr) {
     LinearArgs a = mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, res, ldr, act, out_fp32);
     a.norm_w = norm_w; a.norm_eps = norm_eps;
+    a.wide_ok = klass_hint == 1;          // 1 = decode step: rows are independent sequences
     if (W8 && ws) {                       // e4m3 copy of the same weights: only the weight-stream kernels (M <= 32) take it
         a.W8 = W8; a.wscale = ws;
         LinearArgs t = a;
@@ -249,7 +250,6 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
     if (norm_w) { ProfScope ps(e, K_GEMV, s); return vz_launch_linear(a, s); }     // skinny MFMA stream or GEMV: both fuse the norm
     const bool gemv = vz_gemv_ok(a) || (g_skinny_mode && vz_skinny_ok(a));
     ProfScope ps(e, gemv ? K_GEMV : K_GEMM, s);
-    (void)klass_hint;
     return vz_launch_linear(a, s);
 }
 
@@ -671,11 +671,11 @@ static int lm_head_logits(vz_engine* e, const bf16_t* h, int rows, float* out, h
     const unsigned char* lm8 = W8("llm.lm_head8", (long)e->Vp * H);
     const float* lms = WS("llm.lm_heads", e->Vp);
     if (rc) return rc;
-    if (tp_local(e)) return linear(e, 0, h, H, lm, H, out, c.vocab, rows, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps, lm8, lms);
+    if (tp_local(e)) return linear(e, norm_w ? 1 : 0, h, H, lm, H, out, c.vocab, rows, c.vocab, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps, lm8, lms);
     const size_t local_off = ((size_t)e->tp * rows * e->Vp + 3) & ~(size_t)3;      // the GEMM wants a 16-byte-aligned output base
     { int r = ensure_gather(e, rows, s); if (r) return r; }
     float* local = e->d_gather + local_off;
-    RC(linear(e, 0, h, H, lm, H, local, e->Vp, rows, e->Vp, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps, lm8, lms));
+    RC(linear(e, norm_w ? 1 : 0, h, H, lm, H, local, e->Vp, rows, e->Vp, H, nullptr, nullptr, 0, VZ_ACT_NONE, 1, s, norm_w, c.rms_eps, lm8, lms));
     if (!e->comm && !tp_skip(e)) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
     if (tp_skip(e)) {     // rehearsal: this rank's shard goes to its own chunk, the others stay zero
         VZ_CHECK_HIP(hipMemsetAsync(e->d_gather, 0, (size_t)e->tp * rows * e->Vp * sizeof(float), s));
@@ -897,14 +897,14 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
             if (rc) return rc;
             if (Hkv <= 8 && D == 128 && e->fuse_ok && vz_attn_half_ok(f)) {
                 if (g_decode_fuse == 2)         // attention + O only: the QKV GEMV stays its own launch
-                    RC(linear(e, 0, x, H, f.Wqkv, H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, f.norm_w, c.rms_eps, f.Wqkv8, f.sqkv));
+                    RC(linear(e, 1, x, H, f.Wqkv, H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, f.norm_w, c.rms_eps, f.Wqkv8, f.sqkv));
                 ProfScope ps(e, K_FUSED, s);
                 RC(vz_launch_attn_half(f, s));
                 fused = true;
             }
         }
         if (!fused) {
-        RC(linear(e, 0, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps,
+        RC(linear(e, 1, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps,
                   W8(p + "qkv.w8", (long)QKV * H), WS(p + "qkv.ws", QKV)));
         {
             ProfScope ps(e, K_ATTN_DEC, s);
@@ -915,13 +915,13 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
             a.scale = 0.08838834764831845f;
             RC(vz_launch_attn_decode_fused(a, s));
         }
-        RC(linear(e, 0, att, A, WB(p + "o.w", (long)H * A), A, x, H, B, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
+        RC(linear(e, 1, att, A, WB(p + "o.w", (long)H * A), A, x, H, B, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
                   W8(p + "o.w8", (long)H * A), WS(p + "o.ws", H)));
         }
         RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
-        RC(linear(e, 0, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps,
+        RC(linear(e, 1, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps,
                   W8(p + "gu.w8", 2L * I * H), WS(p + "gu.ws", 2L * I)));
-        RC(linear(e, 0, act, I, WB(p + "down.w", (long)I * H), I, x, H, B, H, I, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
+        RC(linear(e, 1, act, I, WB(p + "down.w", (long)I * H), I, x, H, B, H, I, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
                   W8(p + "down.w8", (long)I * H), WS(p + "down.ws", H)));
         RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
         if (rc) return rc;

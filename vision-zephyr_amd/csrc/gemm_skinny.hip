@@ -526,7 +526,7 @@ bool vz_skinny_fused_norm_ok(const LinearArgs& a) { return g_skinny_mode != 2 &&
 
 bool vz_skinny_ok(const LinearArgs& a) {
     if (a.M < 2 || a.M > 64 || (a.K & 63) != 0 || a.K < 512) return false;
-    if (a.M > 16 && a.norm_w) return false;                                       // 17..64 rows: the caller normalises (no LDS staging)
+    if (a.M > 16 && (a.norm_w || !a.wide_ok)) return false;                                       // 17..64 rows: the caller normalises (no LDS staging)
     if (a.W8 && (!a.wscale || (a.ldw & 15) != 0 || ((uintptr_t)a.W8 & 15) != 0)) return false;
     if (a.act == VZ_ACT_SWIGLU && (a.N % 32) != 0) return false;
     if ((a.lda & 7) != 0 || (a.ldw & 7) != 0) return false;                       // 16-byte fragment loads

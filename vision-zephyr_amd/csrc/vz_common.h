@@ -121,6 +121,10 @@ struct LinearArgs {
     const float* norm_w; float norm_eps;
     // optional e4m3 copy of W (rows [N][ldw] bytes) + one fp32 power-of-two scale per row: GEMV path streams these instead
     const unsigned char* W8 = nullptr; const float* wscale = nullptr;
+    // 17..64 rows may take the MFMA weight stream (rows = independent sequences of a decode batch).  Off for the engine's prefill /
+    // Q-Former linears: there a row's result must not depend on how many rows sit beside it (the tile GEMM's split-K is a
+    // function of N and K only; tests/test_stages_gpu.py::test_qformer), and 32 / 64 / 96 rows must all take the same kernel.
+    bool wide_ok = true;
 };
 int vz_launch_gemm(const LinearArgs& a, hipStream_t s);
 int vz_linear_check_common(const LinearArgs& a);
