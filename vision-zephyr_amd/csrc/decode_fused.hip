@@ -5,17 +5,17 @@
 // Three kernels of 8-16 us each, every one a short HBM burst behind a dependent chain of memory round trips, spend a large part
 // of their time ramping up and draining (QKV / O run at 4.0-4.7 TB/s where the long GEMVs reach 5.6-6.3, the
 // attention moves 8 MB in 16 us).  Here the three are ROLES of one grid, ordered [attention | QKV rows | O rows] by block index:
-//   * an attention workgroup requests its K/V rows first and only then waits for the QKV rows of its KV head (96 producer
-//     workgroups, one agent-scope counter per KV head); the cache streams in under the QKV GEMV instead of after it;
-//   * an O-projection wave requests ALL of its weights (2 rows x 8 KiB, registers) first and only then waits for the eight
-//     head merges; by the time the attention is done its weights have landed - the projection costs a dot product;
+//   * an attention workgroup requests its K/V rows first and only then waits for the QKV rows of its KV head (48 producer
+//     workgroups of 16 rows: 32 of q, 8 of k, 8 of v); the cache streams in under the QKV GEMV instead of after it;
+//   * an O-projection wave requests ALL of its weights (4 rows x 8 KiB, registers) once the QKV rows are in and only then waits
+//     for the eight head merges; by the time the attention is done its weights have landed - the projection costs a dot product;
 //   * two kernel boundaries (1.2-1.9 us each, MI355X_MICROARCH "boundary") disappear.
-// Hand-off (CDNA4 guide section 6 G16, counter form): the producer's payload goes out with sc1 (write-through) stores, every
-// storing wave drains its stores (vmcnt(0)), a workgroup barrier, then ONE lane adds to the counter (relaxed, agent scope); the
-// consumer's lane 0 polls the counter with sc1 loads, a workgroup barrier, then everybody loads the payload with sc1 loads.
-// The counters only grow: the expected value is (step + 1) x producers, `step` being the device-side token counter of
-// vz_llm_decode_steps (the host zeroes counters and step together before the first launch), so nothing is reset inside the launch.
-// Forward progress: waiting workgroups (attention: nsplit x 8; O rows: 512) only ever wait for workgroups with a LOWER role
+// Hand-off (CDNA4 guide section 6 G16, flag form): the producer's payload goes out with sc1 (write-through) stores, every storing
+// wave drains its stores (vmcnt(0)), a workgroup barrier, then ONE lane stores the EPOCH into the workgroup's own flag word (sc1);
+// wave 0 of a consumer polls the flag words of its producers (one or two per lane, sc1 loads, bounded), a workgroup barrier, then
+// everybody loads the payload with sc1 loads.  epoch = step + 1, `step` being the device-side token counter of vz_llm_decode_steps
+// (the host zeroes the flags and step together before the first launch): flags only grow, nothing is reset inside the launch.
+// Forward progress: waiting workgroups (attention: nsplit x 8; O rows: 256) only ever wait for workgroups with a LOWER role
 // position in the dependency chain that are already dispatched: the attention blocks come first in the grid and are fewer than the
 // resident capacity (checked on the host with the occupancy API, otherwise the engine keeps the three-kernel path); the O blocks
 // come last, after every producer has been dispatched.  Every poll loop is bounded: on expiry the workgroup raises the engine's
@@ -42,7 +42,7 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int D = 128, G = 4, CH = 128, NR = CH / 16, PW = G * D + 32;
-constexpr long SPIN_LIMIT = 1L << 22;        // x s_sleep(8) ~ 64 clocks: seconds, far beyond any legitimate wait
+constexpr long SPIN_LIMIT = 1L << 22;        // polls of >= 256 clocks each: seconds, far beyond any legitimate wait
 
 struct FusedLayerParams {
     // residual stream (1 row) and the three weights
