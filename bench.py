@@ -227,6 +227,14 @@ def main():
                         "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4),
                         "traffic": None, "launches": n_l, "total_ms": round(ms, 3),
                         "algorithmic_flops": pre_flops}
+        # the whole image->first-token phase against the MFMA peak: SURVEY section 8(d) algorithmic work of this request -
+        # CLIP 381.9 GFLOP/tile, Q-Former 1186.7 GFLOP/tile at L = 1888, Zephyr prefill 30.224 TFLOP at S = 2048 minus the
+        # all-position lm_head generate() does not run (0.537 TFLOP) - over the measured latency (attention, norms, splice included)
+        if cfg.n_layers == 32 and S == 2048 and n_tiles == 5:
+            ft_flops = n_tiles * (381.9e9 + 1186.7e9) + 30.224e12 - 0.537e12
+            ft_tf = ft_flops / (ttft_sum / args.steps) / 1e12
+            roof_prefill["image_to_first_token"] = {"achieved": round(ft_tf, 1), "unit": "TFLOP/s", "frac": round(ft_tf / MFMA_BF16_PEAK_TF, 4),
+                                                    "algorithmic_flops": ft_flops}
 
     # ---- extra leg (never `value`): the same request on the W8A16 engine of SURVEY config 5 - e4m3 weights with per-row
     # power-of-two scales streamed by the decode GEMV, bf16 activations, bf16 MFMA prefill on the dequantised weights ----

@@ -33,8 +33,12 @@ def build(max_batch):
 
 
 model = build(64)
+for kv in filter(None, os.environ.get("VZ_TUNE", "").split(",")):       # experiments: "knob=value,..." for vz_tune_set
+    from vz_hip import binding as _B
+    _B.check(_B.lib().vz_tune_set(*(int(v) for v in kv.split("="))))
+ROWS = [int(v) for v in os.environ.get("VZ_ROWS", "1,2,4,8,16,32,48,64").split(",")]
 n_new = 64
-for B in (1, 2, 4, 8, 16, 32, 48, 64):
+for B in ROWS:
     ids = torch.stack([synth.synth_ids(64, 32000, image_pos=-1, seed=10 + b) for b in range(B)]).cuda()
     model.generate(input_ids=ids, do_sample=False, max_new_tokens=n_new, eos_token_id=None, pad_token_id=2)
     torch.cuda.synchronize()
