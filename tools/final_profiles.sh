@@ -18,12 +18,13 @@ cp $(find /tmp/prof_final -name "b_kernel_stats.csv") $OUT/bench_kernel_stats.cs
 python3 $GRAFT_REPO_ROOT/tools/analyze_trace.py $(find /tmp/prof_final -name "b_kernel_trace.csv") > $OUT/bench_phase_breakdown.txt
 echo "profile done"; head -8 $OUT/bench_phase_breakdown.txt
 cd $GRAFT_REPO_ROOT
-{
-  echo "== tools/bench_stage1.py"; timeout -k 10 300 python tools/bench_stage1.py 2>&1 | grep -v amdgpu.ids | tail -4
-  echo "== tools/bench_vcr.py"; timeout -k 10 300 python tools/bench_vcr.py 2>&1 | grep batch
-  echo "== tools/bench_vcr.py fp8"; timeout -k 10 300 python tools/bench_vcr.py fp8 2>&1 | grep batch
-  echo "== tools/bench_batched.py"; timeout -k 10 300 python tools/bench_batched.py 2>&1 | grep batch
-  echo "== tools/bench_batched.py 32 fp8"; timeout -k 10 300 python tools/bench_batched.py 32 fp8 2>&1 | grep batch
-} > $OUT/configs.txt
+# every step unbuffered and visible as it goes (a silent step looks hung to the box's watchdog): --line-buffered greps, tee
+run() { echo "== $*" | tee -a $OUT/configs.txt; timeout -k 10 300 python -u "$@" 2>&1 | grep --line-buffered -v amdgpu.ids | grep --line-buffered "batch\|stage-1\|tiles ->\|Zephyr forward\|whole forward" | tee -a $OUT/configs.txt; }
+: > $OUT/configs.txt
+run tools/bench_stage1.py
+run tools/bench_vcr.py
+run tools/bench_vcr.py fp8
+run tools/bench_batched.py
+run tools/bench_batched.py 32 fp8
 timeout -k 10 100 python tools/fused_stamps.py 2048 8 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/fused_stamps.txt
 echo "all done"; cat $OUT/configs.txt | head -30
