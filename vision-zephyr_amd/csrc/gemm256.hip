@@ -461,7 +461,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
             }
             if (finish) {
                 if (tid == 0) {
-                    while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(nseg - 1))
+                    // bounded (guide section 5.6 "bound every spin"): the slices waited for are already past their main loop, so the
+                    // wait is one 256 KiB write; a count that never arrives (or overshoots) must not hang the device
+                    for (int spins = 0; __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(nseg - 1) && spins < (1 << 22); ++spins)
                         __builtin_amdgcn_s_sleep(4);
                     __hip_atomic_store(ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // both counters ready for
                     __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the next launch
