@@ -486,7 +486,9 @@ int g_num_cu_skinny = 0;
 
 template <bool SWIGLU, bool FP8>
 int launch_persist(const SkinnyParams& p, int n_groups, size_t lds, hipStream_t s) {
-    const int per_cu = (160 * 1024) / (int)lds >= 2 ? 2 : 1;
+    // ONE workgroup per CU even where LDS would hold two (5..7 rows): measured 3.85 / 3.88 / 3.94 ms per 5 / 6 / 7-row step
+    // against 3.98 / 4.03 / 4.08 with two (knob 9 = 4) - the eight waves' synchronised bursts again
+    const int per_cu = g_skinny_mode == 4 ? ((160 * 1024) / (int)lds >= 2 ? 2 : 1) : 1;
     const int cap = g_num_cu_skinny * per_cu;
     const int grid = n_groups < cap ? n_groups : cap;
     vz_launch_timed(skinny_persist_kernel<SWIGLU, FP8>, dim3(grid), dim3(512), lds, s, p, n_groups);
