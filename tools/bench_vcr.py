@@ -38,7 +38,7 @@ rng = np.random.default_rng(0)
 frames = [torch.from_numpy(rng.integers(0, 256, (804, 1920, 3), dtype=np.uint8)) for _ in range(MAXB)]     # host memory, as a loader hands them over
 prompts = [synth.synth_ids(L_PROMPT, 32000, image_pos=5, seed=100 + i) for i in range(MAXB)]
 
-for B in (1, 4, 8, 16, 32, 64):
+for B in (() if "stream" in sys.argv[1:] else (1, 4, 8, 16, 32, 64)):
     def run():
         t0 = time.perf_counter()
         tiles = [pre(f, PINS) for f in frames[:B]]                          # H2D + LANCZOS + tiling + normalise on the device
@@ -61,7 +61,8 @@ for B in (1, 4, 8, 16, 32, 64):
 # ---- answers of different lengths (16..128 tokens, as eos would end them): static batches wait for their longest row,
 # ---- continuous batching re-arms a row as soon as its sequence ends ----
 if "stream" in sys.argv[1:]:
-    n_items = 64
+    ROWS = int(os.environ.get("VZ_STREAM_ROWS", "16"))        # rows decoding together; six batches' worth of items
+    n_items = 6 * ROWS
     budgets = [int(b) for b in np.random.default_rng(1).integers(16, 129, n_items)]
     tiles_all = [pre(frames[i % MAXB], PINS) for i in range(n_items)]
     reqs = [{"input_ids": prompts[i % MAXB].unsqueeze(0), "images": tiles_all[i], "images_size": (1920, 804), "max_new_tokens": budgets[i]}
@@ -69,17 +70,17 @@ if "stream" in sys.argv[1:]:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n_tok = 0
-    for i0 in range(0, n_items, MAXB):        # static: every batch runs to its longest budget
-        ids = torch.stack([r["input_ids"][0] for r in reqs[i0:i0 + MAXB]]).to(model.device)
-        out = model.generate(input_ids=ids, images=[r["images"] for r in reqs[i0:i0 + MAXB]], do_sample=False,
-                             max_new_tokens=max(budgets[i0:i0 + MAXB]), eos_token_id=None, pad_token_id=2)
-        n_tok += sum(budgets[i0:i0 + MAXB])
+    for i0 in range(0, n_items, ROWS):        # static: every batch runs to its longest budget
+        ids = torch.stack([r["input_ids"][0] for r in reqs[i0:i0 + ROWS]]).to(model.device)
+        out = model.generate(input_ids=ids, images=[r["images"] for r in reqs[i0:i0 + ROWS]], do_sample=False,
+                             max_new_tokens=max(budgets[i0:i0 + ROWS]), eos_token_id=None, pad_token_id=2)
+        n_tok += sum(budgets[i0:i0 + ROWS])
     torch.cuda.synchronize()
     t_static = time.perf_counter() - t0
     t0 = time.perf_counter()
-    done = dict(model.generate_stream(reqs, eos_token_id=None, rows=MAXB, sync_every=16))
+    done = dict(model.generate_stream(reqs, eos_token_id=None, rows=ROWS, sync_every=16))
     torch.cuda.synchronize()
     t_stream = time.perf_counter() - t0
     assert len(done) == n_items and all(len(done[i]) == budgets[i] for i in range(n_items))
-    print(f"{'fp8 ' if FP8 else ''}{n_items} items, budgets 16..128 tokens ({n_tok} useful tokens), {MAXB} rows: static batches {n_items / t_static:6.2f} items/s, "
+    print(f"{'fp8 ' if FP8 else ''}{n_items} items, budgets 16..128 tokens ({n_tok} useful tokens), {ROWS} rows: static batches {n_items / t_static:6.2f} items/s, "
           f"continuous batching {n_items / t_stream:6.2f} items/s ({t_static / t_stream:4.2f}x)", flush=True)
