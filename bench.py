@@ -117,6 +117,54 @@ def cpu_baseline(cfg_full, S, n_tiles, n_new):
                       f"scaled to {n_tiles} tiles / {cfg_full.n_layers} layers (weights generated in {t_w:.0f}s, untimed)"}
 
 
+def fp8_leg_only(args):
+    """child of the default run: the W8A16 engine on the same request; prints its own JSON object."""
+    import torch
+    from vz_hip import binding as B, synth
+    device = "cuda:0"
+    torch.cuda.set_device(device)
+    n_tiles, n_ids, n_new = 5, 1889, args.new_tokens
+    S = (n_ids - 1) + 32 * n_tiles
+    model8 = build_model(args.layers, device, max_ctx=S + n_new + 16, weight_fp8=True)
+    cfg = model8.arch
+    tiles = synth.synth_tiles(n_tiles, seed=1).to(device, torch.bfloat16)
+    ids = synth.synth_ids(n_ids, cfg.vocab, image_pos=5, seed=2).unsqueeze(0).to(device)
+
+    def step8():
+        tm = {}
+        t0 = time.perf_counter()
+        out = model8.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n_new, eos_token_id=None,
+                              pad_token_id=2, use_cache=True, timing=tm)
+        torch.cuda.synchronize()
+        assert out.shape == (1, n_new)
+        return tm["t_first_token"] - t0, time.perf_counter() - tm["t_first_token"]
+    step8()
+    r8 = [step8() for _ in range(args.steps)]
+    e8 = model8.engine
+    emb8 = model8.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles])[4]
+    _, last8 = e8.prefill(emb8, [S])
+    e8.decode_begin(last8.argmax(-1).to(torch.int32), [S], [S])
+    e8.prof_enable(True, B.K_GEMV)
+    e8.decode_steps(16)
+    torch.cuda.synchronize()
+    n_l8, ms8 = e8.prof_read()
+    e8.prof_enable(False)
+    w_bytes8 = algorithmic_work(cfg, S, n_tiles)[0] // 2 + 4 * (cfg.n_layers * ((cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim
+                                                                                 + 2 * cfg.hidden + 2 * cfg.inter) + cfg.vocab)
+    ach8 = w_bytes8 / (4 * cfg.n_layers + 1) / (ms8 / max(1, n_l8) * 1e-3) / 1e9
+    fp8_leg = {"value": round((n_new - 1) * args.steps / sum(b for _, b in r8), 2), "unit": "tokens/s",
+               "image_to_first_token_ms": round(sum(a for a, _ in r8) / args.steps * 1e3, 2),
+               "dtype": "w8a16: OCP e4m3 weights + per-row 2^e scales (decode stream), bf16 activations, bf16 MFMA prefill on the "
+                        "dequantised weights",
+               "roofline": {"bound": "hbm", "kernel": "gemv_bf16_kernel<.., FP8> (decode weight stream, 1 B per weight)",
+                            "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach8 / HBM_PEAK_GBS, 4),
+                            "traffic": None, "launches": n_l8, "avg_launch_ms": round(ms8 / max(1, n_l8), 5),
+                            "algorithmic_bytes_per_launch": int(w_bytes8 / (4 * cfg.n_layers + 1))}}
+    del model8, e8
+    torch.cuda.empty_cache()
+    print(json.dumps(fp8_leg), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,7 +174,10 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra W8A16 (e4m3 weight stream) measurement")
+    ap.add_argument("--fp8-leg-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.fp8_leg_only:
+        return fp8_leg_only(args)
 
     rank = int(os.environ.get("RANK", "0"))
     tune = os.environ.get("VZ_TUNE", "")   # experiments only: "knob=value,..." for vz_tune_set; reported in config when set
@@ -237,48 +288,23 @@ def main():
                                                     "algorithmic_flops": ft_flops}
 
     # ---- extra leg (never `value`): the same request on the W8A16 engine of SURVEY config 5 - e4m3 weights with per-row
-    # power-of-two scales streamed by the decode GEMV, bf16 activations, bf16 MFMA prefill on the dequantised weights ----
+    # power-of-two scales streamed by the decode GEMV, bf16 activations, bf16 MFMA prefill on the dequantised weights.
+    # Runs in a CHILD process with a time limit (as the tensor-parallel leg does): whatever happens there - an exception, a
+    # stall while the second engine is built - the bf16 line of this process is printed. ----
     fp8_leg = None
     if world == 1 and not args.no_fp8_leg:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--fp8-leg-only", "--steps", str(args.steps), "--layers", str(args.layers),
+               "--new-tokens", str(args.new_tokens)]
         try:
-            del model, eng
-            torch.cuda.empty_cache()
-            model8 = build_model(args.layers, device, max_ctx=S + n_new + 16, weight_fp8=True)
-
-            def step8():
-                tm = {}
-                t0 = time.perf_counter()
-                out = model8.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n_new, eos_token_id=None,
-                                      pad_token_id=2, use_cache=True, timing=tm)
-                torch.cuda.synchronize()
-                assert out.shape == (1, n_new)
-                return tm["t_first_token"] - t0, time.perf_counter() - tm["t_first_token"]
-            step8()
-            r8 = [step8() for _ in range(args.steps)]
-            e8 = model8.engine
-            emb8 = model8.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles])[4]
-            _, last8 = e8.prefill(emb8, [S])
-            e8.decode_begin(last8.argmax(-1).to(torch.int32), [S], [S])
-            e8.prof_enable(True, B.K_GEMV)
-            e8.decode_steps(16)
-            torch.cuda.synchronize()
-            n_l8, ms8 = e8.prof_read()
-            e8.prof_enable(False)
-            w_bytes8 = algorithmic_work(cfg, S, n_tiles)[0] // 2 + 4 * (cfg.n_layers * ((cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim
-                                                                                         + 2 * cfg.hidden + 2 * cfg.inter) + cfg.vocab)
-            ach8 = w_bytes8 / (4 * cfg.n_layers + 1) / (ms8 / max(1, n_l8) * 1e-3) / 1e9
-            fp8_leg = {"value": round((n_new - 1) * args.steps / sum(b for _, b in r8), 2), "unit": "tokens/s",
-                       "image_to_first_token_ms": round(sum(a for a, _ in r8) / args.steps * 1e3, 2),
-                       "dtype": "w8a16: OCP e4m3 weights + per-row 2^e scales (decode stream), bf16 activations, bf16 MFMA prefill on the "
-                                "dequantised weights",
-                       "roofline": {"bound": "hbm", "kernel": "gemv_bf16_kernel<.., FP8> (decode weight stream, 1 B per weight)",
-                                    "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach8 / HBM_PEAK_GBS, 4),
-                                    "traffic": None, "launches": n_l8, "avg_launch_ms": round(ms8 / max(1, n_l8), 5),
-                                    "algorithmic_bytes_per_launch": int(w_bytes8 / (4 * cfg.n_layers + 1))}}
-            del model8, e8
-            torch.cuda.empty_cache()
-        except Exception as ex:       # the bf16 numbers stand on their own
-            fp8_leg = {"value": None, "error": f"{type(ex).__name__}: {ex}"}
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and lines:
+                fp8_leg = json.loads(lines[-1])
+            else:
+                fp8_leg = {"value": None, "error": f"child rc={r.returncode}: {(r.stderr or '')[-300:]}"}
+        except subprocess.TimeoutExpired:
+            fp8_leg = {"value": None, "error": "W8A16 child timed out after 240 s"}
 
     # ---- N > 1: a guarded tensor-parallel leg beside the replica measurement.  Every rank starts a CHILD process that
     # runs this script in tp mode (its own rendezvous port), so a failure or hang inside the collectives cannot take the
