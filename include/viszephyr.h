@@ -34,6 +34,10 @@ extern "C" {
 #define VZ_ERR_STATE 3        /* call order / missing weights      -> Python RuntimeError    */
 #define VZ_ERR_UNSUPPORTED 4  /* reference-unreachable feature     -> NotImplementedError    */
 
+/* values of the async error word (vz_engine_async_error / vz_op_async_error): which bounded device-side wait expired */
+#define VZ_ASYNC_FUSED 1      /* hand-off of the one-launch attention half of a batch-1 decode layer (decode_fused.hip) */
+#define VZ_ASYNC_STREAMK 2    /* stream-K fix-up of the 256^2 GEMM: the tile was written as NaN, never as a sum of stale slots */
+
 typedef void* vz_stream;
 typedef struct vz_engine vz_engine;
 
@@ -220,6 +224,23 @@ int vz_llm_prefill(vz_engine* e, const void* d_embeds, int B, int S, const int* 
 int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, const int* h_next_pos, const int* h_ctx_len,
                         vz_stream stream);
 int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d_logits_dbg, vz_stream stream);
+/* vz_llm_decode_steps rejects (VZ_ERR_ARG) a call whose n steps would take a live row past max_ctx keys or past the rotary
+ * tables; rows parked by vz_llm_decode_set_row(ctx_len 0) saturate on the device instead.
+ *
+ * Sampling tail (hf:generation/utils.py `_sample`, do_sample=True; ref:vis_zephyr/serve/cli.py:171-182 = temperature 0.2 +
+ * HF's default top_k 50): after vz_llm_decode_sampling(enable=1) every decode step draws its token on the device -
+ * logits / temperature, top-k, top-p, then a Gumbel race keyed by Philox4x32-10(seed; vocab index, row, draw counter) - inside
+ * the same per-token hipGraph, so a streamer / stopping-criteria loop reads back 4 bytes per token.  `first_counter` is the
+ * draw counter the next vz_llm_decode_begin starts from.  vz_op_sample: the same kernel on arbitrary fp32 logits rows
+ * (the first token, drawn from the prefill logits with counter 0; tests).  Restated in oracle/sampling_oracle.py. */
+int vz_llm_decode_sampling(vz_engine* e, int enable, float temperature, int top_k, float top_p, unsigned long long seed,
+                           int first_counter);
+/* Streamer / stopping-criteria loop (ref:vis_zephyr/serve/cli.py:155-182 passes a TextStreamer and a KeywordsStoppingCriteria:
+ * one host callback per token): every step's tail also writes its token to ring[row * ring_n + (draw counter mod ring_n)], a
+ * device-visible HOST buffer, so the host keeps a step in flight and reads token t when the event behind step t fires. */
+int vz_llm_decode_ring(vz_engine* e, int* host_visible_ring, int ring_n);
+int vz_op_sample(const float* d_logits, int rows, int cols, float temperature, int top_k, float top_p, unsigned long long seed,
+                 int counter, int* d_ids, vz_stream stream);
 /* how the last vz_llm_decode_steps ran: *graph = 1 when a captured hipGraph was replayed; *comm_in_graph = 1 when the RCCL
  * collectives of a tensor-parallel engine are part of that graph (0 = eager steps, e.g. after RCCL refused the capture) */
 int vz_llm_decode_mode(vz_engine* e, int* graph, int* comm_in_graph);
@@ -227,6 +248,15 @@ int vz_llm_decode_mode(vz_engine* e, int* graph, int* comm_in_graph);
  * every device-side wait is bounded and raises a word when it expires.  Reads and clears that word (blocking): *err != 0 = the
  * outputs since the previous call are invalid. */
 int vz_engine_async_error(vz_engine* e, int* err);
+/* The same word for op-level launches (vz_op_linear* whose 256^2 GEMM took the stream-K tail) on `stream`.  Stream-K state
+ * (fp32 slots, arrival tickets, error word) exists once per (device, stream): launches that share it are stream-ordered.  A wait
+ * that expires raises VZ_ASYNC_STREAMK, leaves the tickets untouched and poisons its tile with NaN; reading the error resets the
+ * tickets of that stream. */
+int vz_op_async_error(vz_stream stream, int* err);
+/* TEST HOOK (tests/test_ops_gpu.py): overwrite the {arrive, ready} ticket pair of stream-K remainder tile `tile` on `stream`. */
+int vz_test_corrupt_streamk(vz_stream stream, int tile, int arrive, int ready);
+/* forget a registered weight (e.g. the e4m3 copy of a bf16 tensor that has been rewritten) */
+int vz_engine_unset_weight(vz_engine* e, const char* name);
 /* Continuous batching.  vz_llm_prefill_rows: vz_llm_prefill into KV-cache rows row0 .. row0+B-1;
  * vz_llm_decode_set_row: (re)arm one row of the running decode batch - next input token, rotary position, context length -
  * without touching the others (a finished row is parked with ctx_len 0 until a new request is prefilled into it). */
@@ -245,6 +275,13 @@ int vz_op_resample_u8(const void* d_src, int h, int w, void* d_tmp, void* d_dst,
                       const int* d_xcoefs, int kx, const int* d_ybounds, const int* d_ycoefs, int ky, vz_stream stream);
 int vz_op_anyres_tiles(const void* d_global, const void* d_resized, int nh, int nw, int paste_x, int paste_y, int grid_w,
                        int grid_h, int side, const void* d_lut, void* d_out, vz_stream stream);
+
+/* ViP "point" overlay on the device (ref:vis_zephyr/model/vip_processor/conversation_generator.py:143-153,170-175: the
+ * `vcr_qa` / `vcr_qar` visual prompt = `ImageDraw.ellipse(box, fill=rgba, outline=rgba)` on a transparent canvas +
+ * `Image.alpha_composite` + convert("RGB")): composites one filled ellipse with the INTEGER box (x0, y0, x1, y1) - the
+ * reference's float box truncated as Pillow's (int) cast does - and colour rgba (r | g << 8 | b << 16 | a << 24) onto the
+ * u8 [h, w, 3] image in place, bit-exact with Pillow (oracle/vip_oracle.py).  Points of one image are applied in call order. */
+int vz_op_vip_point(void* d_image_u8, int h, int w, int x0, int y0, int x1, int y1, unsigned rgba, vz_stream stream);
 
 /* argmax over fp32 logits rows: ids int32 [rows] (first maximal index) */
 int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_stream stream);

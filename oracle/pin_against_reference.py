@@ -99,11 +99,110 @@ def sub(t, n=4096):
     return f[::k][:n].double().numpy().astype(np.float32), k
 
 
+def _round_matrices_in_place(sd):
+    """what a bf16 checkpoint holds: every tensor the oracle's Prec.w touches (matrices, embeddings, class token, learned
+    queries) rounded to bf16; biases and norm scales stay fp32.  `sd` are views of the reference's own parameters, so the
+    reference becomes the W16 model too."""
+    n = 0
+    for k, t in sd.items():
+        if t.ndim >= 2 or k.endswith("class_embedding"):
+            t.copy_(t.to(torch.bfloat16).to(torch.float32))
+            n += 1
+    return n
+
+
+def _top2(logits):
+    v, i = logits.float().topk(2, dim=-1)
+    return i.numpy().astype(np.int64), v.numpy().astype(np.float32)
+
+
+def _case_e(model, cfg, sd, fx, report, check, tag, P, tiles, ids, n_new, t0):
+    """BASELINE configs[1]: prefill at S=512 + n_new greedy tokens through the reference's own generate; the oracle is checked
+    under teacher forcing with the reference's ids (one forward over prompt + generated ids = the decode steps' logits)."""
+    r = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles], None)
+    m = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids, None, None, None, None, [tiles], P=P)
+    check(f"{tag}.splice.embeds", m[4], r[4])
+    S = r[4].shape[1]
+    g = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n_new, use_cache=True,
+                       eos_token_id=None, pad_token_id=2, return_dict_in_generate=True, output_logits=True)
+    gen = g.sequences
+    assert gen.shape == (1, n_new), gen.shape
+    step_ref = torch.stack([x[0].float() for x in g.logits], 0)                      # [n_new, V]
+    print(f"[pin] {tag} reference generate done {time.time() - t0:.0f}s ids[:8]={gen[0, :8].tolist()}", flush=True)
+    full = torch.cat([m[4], O.embed_tokens(sd, gen[0, :-1], P).unsqueeze(0)], 1)
+    _, _, hfin = O.llm_forward(cfg, sd, full, P=P, last_only=True, return_hidden=True)
+    step = hfin[0, S - 1:] @ P.w(sd["lm_head.weight"]).t()
+    check(f"{tag}.step_logits", step, step_ref, tol=5e-5)
+    fx[f"{tag}.generate.ids"] = gen.numpy().astype(np.int64)
+    fx[f"{tag}.step_logits.s64"] = step_ref[:, ::64].numpy().astype(np.float32)
+    fx[f"{tag}.logits.last"] = step_ref[0].numpy().astype(np.float32)
+    fx[f"{tag}.step_top2.ids"], fx[f"{tag}.step_top2.vals"] = _top2(step_ref)
+    return m[4], gen, step_ref
+
+
+def deep_cases(model, cfg, sd, fx, report, check, t0):
+    n_new = 128
+    tiles_a = synth.synth_tiles(3, seed=1)
+    ids_a = synth.synth_ids(32, cfg.vocab, image_pos=5, seed=2).unsqueeze(0)
+    tiles_e = synth.synth_tiles(1, seed=11)
+    ids_e = synth.synth_ids(481, cfg.vocab, image_pos=5, seed=12).unsqueeze(0)
+    # ---------------- case E, fp32 ----------------
+    emb_e, gen_e, step_e = _case_e(model, cfg, sd, fx, report, check, "E", O.FP32, tiles_e, ids_e, n_new, t0)
+    # the BF16-policy oracle (activation rounding at the HIP path's store points) on the same teacher-forced ids: the band
+    m16 = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids_e, None, None, None, None, [tiles_e], P=O.BF16)
+    full = torch.cat([m16[4], O.embed_tokens(sd, gen_e[0, :-1], O.BF16).unsqueeze(0)], 1)
+    _, _, hfin = O.llm_forward(cfg, sd, full, P=O.BF16, last_only=True, return_hidden=True)
+    step16 = hfin[0, emb_e.shape[1] - 1:] @ O.BF16.w(sd["lm_head.weight"]).t()
+    fx["E.bf16_oracle.step_logits.s64"] = step16[:, ::64].numpy().astype(np.float32)
+    fx["E.bf16_oracle.argmax"] = step16.argmax(-1).numpy().astype(np.int64)
+    print(f"[pin] E bf16-policy oracle vs fp32 reference: rel-L2 "
+          f"{float((step16 - step_e).norm() / step_e.norm()):.3e} ({time.time() - t0:.0f}s)", flush=True)
+    # ---------------- W16: the reference itself on bf16-rounded matrices and tiles ----------------
+    lo32_a = model(input_ids=ids_a, images=[tiles_a]).logits
+    n = _round_matrices_in_place(sd)
+    print(f"[pin] rounded {n} tensors of the reference to bf16 in place ({time.time() - t0:.0f}s)", flush=True)
+    ta = tiles_a.to(torch.bfloat16).float()
+    te = tiles_e.to(torch.bfloat16).float()
+    lo_ref = model(input_ids=ids_a, images=[ta]).logits
+    m = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids_a, None, None, None, None, [ta])   # weights are rounded already
+    lo, _ = O.llm_forward(cfg, sd, m[4])
+    check("A16.logits", lo, lo_ref, tol=5e-5)
+    fx["A16.logits.last"] = lo_ref[0, -1].numpy().astype(np.float32)
+    report["A.weight_rounding_rel_l2"] = float((lo_ref - lo32_a).norm() / lo32_a.norm())
+    print(f"[pin] A: weight rounding alone moves the logits by rel-L2 {report['A.weight_rounding_rel_l2']:.3e}", flush=True)
+    gen_a = model.generate(input_ids=ids_a, images=[ta], do_sample=False, max_new_tokens=6, use_cache=True,
+                           eos_token_id=None, pad_token_id=2)
+    fx["A16.generate.ids"] = gen_a.numpy().astype(np.int64)
+    tower = model.get_vision_tower()
+    hs_ref = tower.vision_tower(ta, output_hidden_states=True)["hidden_states"]
+    hs = O.clip_hidden_states(cfg, sd, ta)
+    check("A16.clip.hs24", hs[24], hs_ref[24])
+    fused = tower(ta)
+    check("A16.fused", O.fusion(cfg, hs), fused)
+    text_ids = ids_a[0][ids_a[0] != O.IMAGE_TOKEN_INDEX]
+    te_a = model.get_model().embed_tokens(text_ids).unsqueeze(0).expand(3, -1, -1)
+    check("A16.encode_images", O.qformer(cfg, sd, O.fusion(cfg, hs), te_a), model.encode_images(ta, te_a))
+    _, gen16, step16_ref = _case_e(model, cfg, sd, fx, report, check, "E16", O.FP32, te, ids_e, n_new, t0)
+    # W16 logits on the fp32 run's ids (teacher forcing with E.generate.ids) so FP32 and W16 are comparable step by step
+    m = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids_e, None, None, None, None, [te])
+    full = torch.cat([m[4], O.embed_tokens(sd, gen_e[0, :-1], O.FP32).unsqueeze(0)], 1)
+    _, _, hfin = O.llm_forward(cfg, sd, full, last_only=True, return_hidden=True)
+    stepw = hfin[0, m[4].shape[1] - 1:] @ sd["lm_head.weight"].t()
+    fx["E.w16_on_fp32_ids.step_logits.s64"] = stepw[:, ::64].numpy().astype(np.float32)
+    report["E.weight_rounding_rel_l2"] = float((stepw - step_e).norm() / step_e.norm())
+    report["E.first_id_divergence_fp32_vs_w16"] = int((gen16[0] != gen_e[0]).nonzero()[0]) if bool((gen16 != gen_e).any()) else -1
+    print(f"[pin] E: weight rounding alone moves the step logits by rel-L2 {report['E.weight_rounding_rel_l2']:.3e}; "
+          f"fp32 and W16 greedy ids first differ at step {report['E.first_id_divergence_fp32_vs_w16']}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--llm-layers", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--deep", action="store_true",
+                    help="also pin case E (BASELINE configs[1]: 1 tile + 481 ids -> S=512, 128 greedy tokens) and re-run cases "
+                         "A and E through the reference with its matrices rounded to bf16 in place (the W16 model)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -227,6 +326,9 @@ def main():
         check("D.encode_images.cls_patch", O.qformer(cfg, sd, fused_d, te_d), model.encode_images(tiles_d, te_ref[:2]))
     finally:
         tower.select_feature = "patch"
+
+    if args.deep:
+        deep_cases(model, cfg, sd, fx, report, check, t0)
 
     meta = dict(llm_layers=args.llm_layers, seed=args.seed, report=report,
                 torch=torch.__version__, transformers=__import__("transformers").__version__,

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
     from vz_hip import binding
     assert declared == set(binding.SYMBOLS), declared ^ set(binding.SYMBOLS)
     handle = binding.load_library(lib)          # raises AttributeError on a missing export
-    assert handle.vz_abi_version() == 4
+    assert handle.vz_abi_version() == binding.ABI_VERSION == 5
     assert handle.vz_target_arch() == b"gfx950"
     assert handle.vz_last_error() == b""
 
@@ -64,7 +64,9 @@ def test_graft_entry_abi_assertion_matches_library():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "__graft_entry__.py")).read()
-    want = int(re.search(r"vz_abi_version\(\) == (\d+)", src).group(1))
+    assert "vz_abi_version() == binding.ABI_VERSION" in src
+    from vz_hip import binding
+    want = binding.ABI_VERSION
     eng = open(os.path.join(root, "vision-zephyr_amd", "csrc", "engine.hip")).read()
     have = int(re.search(r"vz_abi_version\(void\) \{ return (\d+); \}", eng).group(1))
     assert want == have

@@ -116,3 +116,42 @@ def test_loader_rejects_what_the_engine_cannot_do():
         load_pretrained_model("x", None, "llava-7b")
     with pytest.raises(NotImplementedError):
         load_pretrained_model("x", None, "vis-zephyr-7b", load_4bit=True)
+
+
+def test_prepare_inputs_for_generation_reattaches_images():
+    """a4 (ref:vis_zephyr/model/language_model/vis_zephyr.py:144-170): pass-through that pops `images` / `images_size`, and puts
+    them back only when they were given."""
+    from vis_zephyr.model import VisZephyrForCausalLM
+    f = VisZephyrForCausalLM.prepare_inputs_for_generation
+    ids = torch.tensor([[1, 2, 3]])
+    img = [torch.zeros(1, 3, 336, 336)]
+    out = f(None, ids, past_key_values="pkv", inputs_embeds=None, attention_mask="m", images=img, images_size=[(1, 2)])
+    assert out["input_ids"] is ids and out["past_key_values"] == "pkv" and out["attention_mask"] == "m"
+    assert out["images"] is img and out["images_size"] == [(1, 2)]
+    out = f(None, ids, use_cache=True)
+    assert "images" not in out and "images_size" not in out and out["use_cache"] is True and out["inputs_embeds"] is None
+
+
+def test_auto_registration_and_hub_cache_resolution(tmp_path, monkeypatch):
+    """ref:vis_zephyr/model/language_model/vis_zephyr.py:173-174 registers the config / model with HF's Auto classes; hub ids
+    resolve through the local cache only."""
+    import json
+    from transformers import AutoConfig, AutoModelForCausalLM
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    from vz_hip import weights as W
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    json.dump({"model_type": "vis_zephyr", "hidden_size": 4096, "mm_vision_tower": "openai/clip-vit-large-patch14-336"}, open(d / "config.json", "w"))
+    c = AutoConfig.from_pretrained(str(d))
+    assert type(c) is VisZephyrConfig and c.model_type == "vis_zephyr" and c.mm_vision_tower == "openai/clip-vit-large-patch14-336"
+    assert AutoModelForCausalLM._model_mapping[VisZephyrConfig] is VisZephyrForCausalLM
+    snap = tmp_path / "hub" / "models--openai--clip-vit-large-patch14-336" / "snapshots" / "abc"
+    snap.mkdir(parents=True)
+    monkeypatch.setenv("HF_HUB_CACHE", str(tmp_path / "hub"))
+    import huggingface_hub.constants as hc
+    monkeypatch.setattr(hc, "HF_HUB_CACHE", str(tmp_path / "hub"), raising=False)
+    assert W.resolve_hub_path("openai/clip-vit-large-patch14-336") == str(snap)
+    assert W.resolve_hub_path(str(d)) == str(d)
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        W.resolve_hub_path("HuggingFaceH4/zephyr-7b-beta")

@@ -680,3 +680,62 @@ def _fuzz_attention_cases(n=14, seed=4321):
 @pytest.mark.parametrize("case", _fuzz_attention_cases(), ids=lambda c: f"{c[0]}-B{c[1]}-Sq{c[2]}-Sk{c[3]}-H{c[4]}/{c[5]}-D{c[6]}-c{int(c[7])}-w{c[9]}")
 def test_attention_shape_fuzz(B, case):
     test_attention(B, case)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stream-K state is per (device, stream); an expired fix-up wait raises the async error word and poisons its tile
+# ---------------------------------------------------------------------------------------------------------------------
+def test_gemm256_streamk_two_streams_do_not_share_tickets(B):
+    """Round 1 kept ONE process-wide set of stream-K slots / tickets: two streams (or two engines) running stream-K GEMMs at the
+    same time met on it.  Now every (device, stream) has its own: interleaved launches on two streams give the results of
+    the same launches run alone."""
+    M, N, K = 640, 1100, 4096           # 3 x 5 = 15 tiles on 256 CUs: the whole launch is a stream-K tail when forced
+    x1, w1 = _rand((M, K), 1.0, 70).bfloat16(), _rand((N, K), 0.05, 71).bfloat16()
+    x2, w2 = _rand((M, K), 1.0, 72).bfloat16(), _rand((N, K), 0.05, 73).bfloat16()
+    try:
+        B.check(B.lib().vz_tune_set(4, 2))
+        alone1 = B.linear(x1, w1, out_fp32=True, impl=2)
+        alone2 = B.linear(x2, w2, out_fp32=True, impl=2)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs1, outs2 = [], []
+        for _ in range(8):
+            with torch.cuda.stream(s1):
+                outs1.append(B.linear(x1, w1, out_fp32=True, impl=2))
+            with torch.cuda.stream(s2):
+                outs2.append(B.linear(x2, w2, out_fp32=True, impl=2))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            assert B.op_async_error() == 0
+        with torch.cuda.stream(s2):
+            assert B.op_async_error() == 0
+    finally:
+        B.check(B.lib().vz_tune_set(4, 1))
+    for o in outs1:
+        assert torch.equal(o, alone1)
+    for o in outs2:
+        assert torch.equal(o, alone2)
+
+
+def test_gemm256_streamk_expired_wait_raises_and_poisons(B):
+    """Tickets that no launch can complete from (here: `ready` preset beyond the slice count of remainder tile 0): the finisher's
+    bounded wait expires -> the launch ENDS, the async error word reads VZ_ASYNC_STREAMK, that tile is NaN (never a sum of
+    stale slots), every other tile is right; reading the error resets the tickets and the next launch is clean."""
+    M, N, K = 640, 1100, 4096
+    x, w = _rand((M, K), 1.0, 74).bfloat16(), _rand((N, K), 0.05, 75).bfloat16()
+    try:
+        B.check(B.lib().vz_tune_set(4, 2))
+        good = B.linear(x, w, out_fp32=True, impl=2)
+        assert B.op_async_error() == 0
+        B.check(B.lib().vz_test_corrupt_streamk(B.stream_ptr(), 0, 0, 100))
+        bad = B.linear(x, w, out_fp32=True, impl=2)
+        torch.cuda.synchronize()
+        assert B.op_async_error() == B.VZ_ASYNC_STREAMK
+        nan = torch.isnan(bad)
+        assert nan.any() and int(nan.sum()) <= 256 * 256, int(nan.sum())
+        assert torch.equal(bad[~nan], good[~nan])
+        assert B.op_async_error() == 0                      # cleared, tickets reset
+        again = B.linear(x, w, out_fp32=True, impl=2)
+        assert torch.equal(again, good) and B.op_async_error() == 0
+    finally:
+        B.check(B.lib().vz_tune_set(4, 1))

@@ -1,0 +1,172 @@
+"""The device-side sampling tail (sampling.hip) against oracle/sampling_oracle.py draw for draw, its distribution against the
+warped softmax, and the generate paths that use it (bulk steps, streamer ring, eager = graph, HIP/CUDA_LAUNCH_BLOCKING)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _logits(rows, V, seed, scale=2.5):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(rows, V, generator=g) * scale).float()
+
+
+@pytest.mark.parametrize("T,k,p,V", [(0.2, 50, 1.0, 32000), (0.7, 0, 0.9, 32000), (1.0, 20, 0.5, 32001), (0.1, 50, 0.95, 32000),
+                                     (1.3, 0, 1.0, 4096), (0.7, 5, 0.3, 1000)])
+def test_draw_equals_oracle(T, k, p, V):
+    from oracle import sampling_oracle as S
+    from vz_hip import binding as B
+    rows = 24
+    x = _logits(rows, V, seed=V + k)
+    seed = 0x1234_5678_9ABC_DEF0
+    bad = 0
+    for counter in (0, 1, 77):
+        got = B.sample(x.cuda(), T, k, p, seed, counter).cpu().tolist()
+        for r in range(rows):
+            xr = x[r].numpy()
+            want, margin = S.draw(xr, T, k, p, seed, counter, row=r, return_margin=True)
+            # the top-p cut is a cumulative sum (integer mass on the device, fp64 here): its single boundary token may fall on
+            # either side; nothing else that the warpers filter may ever be drawn
+            loose = np.isfinite(S.warp(xr, T, k, min(1.0, p + 1e-5))) if p < 1.0 else np.isfinite(S.warp(xr, T, k, p))
+            assert loose[got[r]], f"row {r}: drew token {got[r]}, which the warpers filter"
+            if got[r] != want:
+                strict = np.isfinite(S.warp(xr, T, k, max(1e-6, p - 1e-5)))
+                # a different token only where the race is a near-tie in fp32 (logf's last place) or at the top-p boundary token
+                assert margin < 1e-3 or not strict[got[r]] or not strict[want], (r, counter, got[r], want, margin)
+                bad += 1
+    assert bad <= 2, f"{bad} of {3 * rows} draws differ from the oracle"
+
+
+def test_distribution_chi_square():
+    from oracle import sampling_oracle as S
+    from vz_hip import binding as B
+    V, rows = 512, 8192
+    base = _logits(1, V, seed=5, scale=1.5)
+    x = base.expand(rows, V).contiguous().cuda()
+    T, k, p = 0.8, 40, 0.9
+    pr = S.probs(base[0].numpy(), T, k, p)
+    cnt = np.zeros(V)
+    n = 0
+    for counter in range(4):
+        ids = B.sample(x, T, k, p, 99, counter).cpu().numpy()
+        np.add.at(cnt, ids, 1)
+        n += rows
+    assert cnt[pr == 0].sum() == 0, "a filtered token was drawn"
+    big = pr * n >= 5
+    chi2 = float((((cnt - pr * n) ** 2) / (pr * n))[big].sum())
+    dof = int(big.sum()) - 1
+    assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
+
+
+@pytest.fixture(scope="module")
+def model():
+    from vz_hip import synth
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    cfg = synth.ArchConfig(n_layers=2)
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=2, num_attention_heads=32,
+                         num_key_value_heads=8, vocab_size=cfg.vocab, rms_norm_eps=1e-5, sliding_window=4096, eos_token_id=2, pad_token_id=2)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    return VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=256, max_tiles=1, max_text=32)
+
+
+class _Streamer:
+    def __init__(self):
+        self.puts, self.ended = [], False
+
+    def put(self, v):
+        self.puts.append(v.reshape(-1).tolist())
+
+    def end(self):
+        self.ended = True
+
+
+def test_sampled_generate_paths_agree(model):
+    """same seed: bulk graph steps = eager steps = the streamer / stopping-criteria path (one step in flight, tokens through the
+    host-visible ring); the first draws equal the oracle's draws on the engine's own logits."""
+    from oracle import sampling_oracle as S
+    from vz_hip import synth
+    ids = synth.synth_ids(12, 32000, image_pos=-1, seed=21).unsqueeze(0)
+    kw = dict(input_ids=ids, do_sample=True, temperature=0.9, top_p=0.95, max_new_tokens=12, eos_token_id=None, seed=4242)
+    a = model.generate(**kw)
+    os.environ["VZ_NO_GRAPH"] = "1"
+    try:
+        b = model.generate(**kw)
+    finally:
+        del os.environ["VZ_NO_GRAPH"]
+    st = _Streamer()
+    seen = []
+    c = model.generate(streamer=st, stopping_criteria=[lambda i, s, **k: seen.append(i.shape[1]) or False], **kw)
+    assert a.shape == (1, 12) and a.tolist() == b.tolist() == c.tolist()
+    assert st.ended and st.puts[0] == [] and [p[0] for p in st.puts[1:]] == a[0].tolist() and seen == list(range(1, 13))
+    # HF's default top_k = 50 is in force when the caller names none (the reference's CLI); top_k=None switches it off
+    d = model.generate(top_k=50, **kw)
+    assert d.tolist() == a.tolist()
+    # first token: drawn from the prefill logits with counter 0; second: from the first decode step's logits with counter 1
+    out = model(input_ids=ids)
+    want0 = S.draw(out.logits[0, -1].float().cpu().numpy(), 0.9, 50, 0.95, 4242, 0)
+    assert int(a[0, 0]) == want0
+    ids2 = torch.cat([ids, a[:, :1].cpu()], 1)
+    want1, margin = S.draw(model(input_ids=ids2).logits[0, -1].float().cpu().numpy(), 0.9, 50, 0.95, 4242, 1, return_margin=True)
+    assert int(a[0, 1]) == want1 or margin < 5e-2        # decode-step logits = prefill logits only to bf16 accuracy
+    # different seeds differ somewhere in 12 tokens at this temperature
+    e = model.generate(**{**kw, "seed": 4243})
+    assert e.tolist() != a.tolist()
+
+
+def test_streamer_stop_and_greedy_ring(model):
+    from vz_hip import synth
+    ids = synth.synth_ids(12, 32000, image_pos=-1, seed=22).unsqueeze(0)
+    g = model.generate(input_ids=ids, do_sample=False, max_new_tokens=10, eos_token_id=None)
+    st = _Streamer()
+    h = model.generate(input_ids=ids, do_sample=False, max_new_tokens=10, eos_token_id=None, streamer=st,
+                       stopping_criteria=[lambda i, s, **k: i.shape[1] >= 7])
+    assert h[0].tolist() == g[0].tolist()[:7] and st.ended
+    # the engine is clean afterwards: the speculative step left no state behind
+    g2 = model.generate(input_ids=ids, do_sample=False, max_new_tokens=10, eos_token_id=None)
+    assert g2.tolist() == g.tolist()
+
+
+_CHILD = r"""
+import json, sys, torch
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {repo!r} + "/vision-zephyr_amd")
+from vz_hip import synth
+from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+cfg = synth.ArchConfig(n_layers=1)
+hf = VisZephyrConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=1, num_attention_heads=32, num_key_value_heads=8,
+                     vocab_size=32000, rms_norm_eps=1e-5, sliding_window=4096, eos_token_id=2, pad_token_id=2)
+hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"; hf.mm_patch_merge_type = "flat"
+m = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=128, max_tiles=1, max_text=32)
+ids = synth.synth_ids(16, 32000, image_pos=3, seed=2).unsqueeze(0)
+tiles = synth.synth_tiles(1, seed=1)
+class St:
+    def __init__(s): s.n = 0
+    def put(s, v): s.n += 1
+    def end(s): pass
+st = St()
+out = m.generate(input_ids=ids, images=[tiles], do_sample=True, temperature=0.2, max_new_tokens=8, eos_token_id=None, seed=7,
+                 streamer=st, stopping_criteria=[lambda i, s, **k: False])
+print("RESULT " + json.dumps(dict(ids=out[0].tolist(), puts=st.n)))
+"""
+
+
+def test_cli_path_under_launch_blocking():
+    """ref:vis_zephyr/serve/cli.py:197 sets CUDA_LAUNCH_BLOCKING=1 before it does anything: the path the CLI takes -
+    image, streamer, stopping criteria, do_sample at temperature 0.2 - must give the same ids with and without it."""
+    def run(extra):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", _CHILD.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        return json.loads(line[7:])
+    plain = run({})
+    blocking = run({"CUDA_LAUNCH_BLOCKING": "1", "HIP_LAUNCH_BLOCKING": "1", "AMD_SERIALIZE_KERNEL": "3"})
+    assert plain["ids"] == blocking["ids"] and len(plain["ids"]) == 8 and plain["puts"] == blocking["puts"] == 9

@@ -512,6 +512,26 @@ def test_fp8_weight_engine_matches_quantized_oracle(env):
             assert float(margin[t]) < 2e-3, f"step {t}: id {int(got[0, t])} vs oracle {int(ref_ids[0, t])}, margin {float(margin[t]):.2e}"
             break
     record("generate fp8", got=got[0].tolist(), oracle_bf16_quantized=ref_ids[0].tolist(), min_margin=float(margin.min()))
+    # A SECOND load into the same fp8 engine (base then finetune, LoRA re-merge): the e4m3 copies are derived data and must follow
+    # the rewritten bf16 tensors - decode (fp8 stream) and prefill (bf16) keep computing with ONE model.
+    sd2 = {k: v.cpu() for k, v in synth.iter_state_dict(cfg, 1, device=model.device, prefixes=("model.layers.", "lm_head", "model.norm", "model.embed"))}
+    eng.load_weights(sd2.items())
+    sdq2 = O.quantize_state_dict({**sd, **sd2})
+    qkv2 = torch.cat([sdq2[f"model.layers.1.self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+    assert not torch.equal(qkv2, qkv)
+    assert torch.equal(eng.w["llm.1.qkv.w"].float().cpu(), qkv2)
+    assert torch.equal(quant.dequantize_rows(eng.w["llm.1.qkv.w8"], eng.w["llm.1.qkv.ws"]).cpu(), qkv2)
+    emb2 = eng.embed_tokens(ids).unsqueeze(0)
+    full2, _ = eng.prefill(emb2, [40], all_logits=True, last_logits=False)
+    eng.prefill(emb2[:, :S0].contiguous(), [S0], all_logits=False, last_logits=True)
+    eng.decode_begin(ids[S0:S0 + 1].to(torch.int32), [S0], [S0])
+    _, lg2 = eng.decode_steps(1, return_logits=True)
+    check_close("fp8 decode step vs prefill after a second load", lg2[0, 0], full2[0, S0], 3e-2, 1.6 * e_or + 5e-4)
+    # resize_token_embeddings on the fp8 engine: lm_head8 / lm_heads are rebuilt at the new size (finalize used to fail on the stale ones)
+    model.resize_token_embeddings(cfg.vocab + 1)
+    assert eng.w["llm.lm_head8"].shape[0] == cfg.vocab + 1 and eng.w["llm.lm_heads"].shape[0] == cfg.vocab + 1
+    out_r = model.generate(input_ids=ids.unsqueeze(0), do_sample=False, max_new_tokens=3, eos_token_id=None, pad_token_id=2)
+    assert out_r.shape == (1, 3)
     del model
     torch.cuda.empty_cache()
 
@@ -597,6 +617,22 @@ def test_sliding_window_and_context_capacity(env):
     assert out.shape == (1, 12)
     with pytest.raises(ValueError):
         model.generate(input_ids=ids[:S].unsqueeze(0), do_sample=False, max_new_tokens=13, eos_token_id=None)
+    # the same edge at the C ABI (a caller that steps the engine itself): the n steps of a call must fit the cache row and the
+    # rotary tables, checked on the host before anything is launched ...
+    eng.decode_begin(ids[:1].to(torch.int32), [110], [110])          # 110 cached, the next token sees 111 keys
+    with pytest.raises(ValueError, match="max_ctx"):
+        eng.decode_steps(3)                                            # 111 + 3 - 1 = 113 > 112
+    assert eng.decode_steps(2).shape == (1, 2)                          # 112: the last slot of the row
+    with pytest.raises(ValueError, match="max_ctx"):
+        eng.decode_steps(1)
+    # ... while a PARKED row (continuous batching: context 0, position 0) may step for ever: the step tail saturates its slot /
+    # length / position on the device instead of walking out of its cache row
+    eng.decode_begin(torch.zeros(1, dtype=torch.int32), [0], [0])
+    for _ in range(3):
+        eng.decode_steps(64)
+    torch.cuda.synchronize()
+    out2 = model.generate(input_ids=ids[:S].unsqueeze(0), do_sample=False, max_new_tokens=12, eos_token_id=None)
+    assert out2.tolist() == out.tolist()
     del model
     torch.cuda.empty_cache()
 

@@ -172,6 +172,18 @@ def test_rccl_call_sites_on_one_rank():
     assert torch.equal(logits, ref_logits)
     assert torch.equal(new_ids, ref_ids)
     assert again.shape == new_ids.shape
+    # The captured TP decode graph holds the gathered-logits buffer: a forward with MORE logits rows between two generates
+    # re-allocates it (ensure_gather), so the graph must be dropped and captured again, not replayed on the freed pointer.
+    try:
+        B.check(B.lib().vz_tune_set(7, 1))
+        _, ids_a = run()
+        big = eng.embed_tokens(synth.synth_ids(100, cfg.vocab, image_pos=-1, seed=6)).unsqueeze(0)
+        eng.prefill(big, [100], all_logits=True, last_logits=False)          # 100 rows of logits > anything gathered so far
+        _, ids_b = run()
+        assert eng.decode_mode() == (True, True)
+    finally:
+        B.check(B.lib().vz_tune_set(7, 0))
+    assert torch.equal(ids_a, ref_ids) and torch.equal(ids_b, ref_ids)
     assert gathered.shape == (1, 3, cfg.hidden) and torch.equal(gathered[0], x[0, :3])
 
 

@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void fusion_kernel(const bf16_t* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int cols, int* __restrict__ ids,
                                                       int* __restrict__ pos, int* __restrict__ slot, int* __restrict__ len,
-                                                      int* __restrict__ out_ids, int out_stride, const int* __restrict__ step) {
+                                                      int* __restrict__ out_ids, int out_stride, const int* __restrict__ step,
+                                                      int max_ctx, int rope_max, int* __restrict__ ring, int ring_n) {
     __shared__ float sv[16];
     __shared__ int si[16];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -268,13 +269,17 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
         if (bi == 0x7fffffff) bi = 0;  // all-NaN row
         ids[row] = bi;
         if (out_ids) out_ids[(size_t)row * out_stride + (step ? *step : 0)] = bi;
-        if (pos) pos[row] += 1;
-        if (slot) slot[row] += 1;
-        if (len) len[row] += 1;
+        if (ring) ring[(size_t)row * ring_n + ((unsigned)step[1] % (unsigned)ring_n)] = bi;     // host-visible ring, slot = draw counter
+        // saturating advance: a live row is kept inside the cache by the host's capacity check (vz_llm_decode_steps); a parked row
+        // of a continuous batch steps for ever and must stay inside its own cache row / the rotary tables
+        if (pos && pos[row] + 1 < rope_max) pos[row] += 1;
+        if (len && len[row] < max_ctx) { len[row] += 1; if (slot) slot[row] += 1; }
     }
 }
 
-__global__ void step_advance_kernel(int* step) { *step += 1; }
+// step[0] = index of the step inside this vz_llm_decode_steps call; step[1] = tokens drawn since vz_llm_decode_begin (the
+// Philox counter of the sampling tail)
+__global__ void step_advance_kernel(int* step) { step[0] += 1; step[1] += 1; }
 
 // vocab-parallel logits after the all-gather: gathered[r][row][j] (j < Vp, zero-padded shards) -> out[row][r*Vp + j]
 __global__ __launch_bounds__(256) void repack_logits_kernel(const float* __restrict__ g, float* __restrict__ out, int rows, int Vp, int V, int tp) {
@@ -369,9 +374,9 @@ int vz_launch_fusion(const bf16_t* hs_base, long layer_stride, int first_layer, 
 }
 
 int vz_launch_argmax(const float* logits, int rows, int cols, int* ids, int* pos, int* slot, int* len, int* out_ids,
-                     int out_stride, const int* step, hipStream_t s) {
-    VZ_CHECK_ARG(logits && ids && rows > 0 && cols > 0, "argmax: bad argument");
-    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, s, logits, cols, ids, pos, slot, len, out_ids, out_stride, step);
+                     int out_stride, const int* step, int max_ctx, int rope_max, int* ring, int ring_n, hipStream_t s) {
+    VZ_CHECK_ARG(logits && ids && rows > 0 && cols > 0 && (!ring || (step && ring_n > 0)), "argmax: bad argument");
+    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, s, logits, cols, ids, pos, slot, len, out_ids, out_stride, step, max_ctx, rope_max, ring, ring_n);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }

@@ -38,7 +38,7 @@ void vz_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vz_last_error(void) { return g_err; }
-extern "C" int vz_abi_version(void) { return 4; }
+extern "C" int vz_abi_version(void) { return 5; }
 extern "C" const char* vz_target_arch(void) { return "gfx950"; }
 
 // ------------------------------------------------------------------------------------------------
@@ -49,7 +49,7 @@ static LinearArgs mk_linear(const void* A, int lda, const void* W, int ldw, void
     LinearArgs a;
     a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.C = C; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K; a.bias = bias; a.residual = (const bf16_t*)residual; a.ldr = ldr;
-    a.act = act; a.out_fp32 = out_fp32; a.norm_w = nullptr; a.norm_eps = 0.f;
+    a.act = act; a.out_fp32 = out_fp32; a.norm_w = nullptr; a.norm_eps = 0.f; a.err = nullptr;
     return a;
 }
 
@@ -130,7 +130,7 @@ extern "C" int vz_op_attention_decode_fused(const void* qkv, void* kc, void* vc,
     return vz_launch_attn_decode_fused(a, (hipStream_t)s);
 }
 extern "C" int vz_op_argmax(const float* logits, int rows, int cols, int* ids, vz_stream s) {
-    return vz_launch_argmax(logits, rows, cols, ids, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (hipStream_t)s);
+    return vz_launch_argmax(logits, rows, cols, ids, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0, (hipStream_t)s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -162,6 +162,13 @@ struct vz_engine {
     bool fuse_ok = true;         // the one-launch attention half fits the device (resident slots for its waiting workgroups)
     bool comm_graph_ok = true;   // RCCL collectives captured into the decode graph (cleared if a capture is refused -> eager steps)
     int dec_len_max = 0;         // host-side bound on the longest row's visible keys (grows by one per launched step)
+    // host mirror of the device-side decode state, per row: keys visible to the NEXT step, its rotary position, and whether the
+    // row is parked (continuous batching: ctx_len 0, steps harmlessly, never checked against the capacity)
+    std::vector<int> h_len, h_pos; std::vector<char> h_parked;
+    // sampling tail (vz_llm_decode_sampling): off = greedy argmax
+    int samp_on = 0, samp_top_k = 0, samp_ctr0 = 0; float samp_temp = 1.f, samp_top_p = 1.f; unsigned samp_seed[2] = {0, 0};
+    int* ring = nullptr; int ring_n = 0;   // host-visible token ring of the streamer path (vz_llm_decode_ring)
+    hipStream_t last_stream = nullptr;   // stream of the last stage call (vz_engine_async_error resets that stream's stream-K tickets)
     int dec_nsplit = 1;          // context splits of the decode attention for the steps being launched
     float* d_logits = nullptr;   // [max_batch, vocab] fp32
     bf16_t* d_xnorm = nullptr;   // [64, hidden]: normalised rows of a 5..16-row decode batch (the MFMA weight stream reads them from L2)
@@ -171,7 +178,7 @@ struct vz_engine {
     int* d_ferr = nullptr;        // raised by a bounded device-side wait that expired
     int nsplit = 32;                 // upper bound: a split takes >= 128 keys, the splits beyond ceil(len / 128) leave at once
     hipStream_t cap_stream = nullptr;   // stream capture is not allowed on the legacy null stream torch hands us
-    hipGraphExec_t dec_graph = nullptr; int dec_graph_B = 0, dec_graph_n = 0, dec_graph_nsplit = 0, dec_graph_fuse = -1; int* dec_graph_out = nullptr; char* dec_graph_arena = nullptr;
+    hipGraphExec_t dec_graph = nullptr; int dec_graph_B = 0, dec_graph_n = 0, dec_graph_nsplit = 0, dec_graph_fuse = -1; long dec_graph_samp[6] = {0, 0, 0, 0, 0, 0}; int* dec_graph_out = nullptr; char* dec_graph_arena = nullptr;
     int* h_pinned = nullptr;     // pinned staging for small host->device uploads
     size_t h_pinned_ints = 0;
     // profiling
@@ -231,7 +238,7 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
                   int N, int K, const float* bias, const bf16_t* res, int ldr, int act, int out_fp32, hipStream_t s,
                   const float* norm_w = nullptr, float norm_eps = 0.f, const unsigned char* W8 = nullptr, const float* ws = nullptr) {
     LinearArgs a = mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, res, ldr, act, out_fp32);
-    a.norm_w = norm_w; a.norm_eps = norm_eps;
+    a.norm_w = norm_w; a.norm_eps = norm_eps; a.err = e->d_ferr; e->last_stream = s;
     a.wide_ok = klass_hint == 1;          // 1 = decode step: rows are independent sequences
     if (W8 && ws) {                       // e4m3 copy of the same weights: only the weight-stream kernels (M <= 32) take it
         a.W8 = W8; a.wscale = ws;
@@ -355,10 +362,30 @@ extern "C" int vz_engine_destroy(vz_engine* e) {
     return VZ_OK;
 }
 
+// The captured decode graph freezes every pointer its kernels take (weights, rotary tables, the gathered-logits buffer, the
+// workspace): whoever replaces one of them drops the graph, the next vz_llm_decode_steps captures again.
+static int drop_decode_graph(vz_engine* e) {
+    if (!e->dec_graph) return VZ_OK;
+    VZ_CHECK_HIP(hipDeviceSynchronize());       // a replay may still be running
+    (void)hipGraphExecDestroy(e->dec_graph);
+    e->dec_graph = nullptr;
+    return VZ_OK;
+}
+
 extern "C" int vz_engine_set_weight(vz_engine* e, const char* name, const void* d_ptr, int dtype, long n_elems) {
     VZ_CHECK_ARG(e && name && d_ptr && dtype >= 0 && dtype <= 2 && n_elems > 0, "set_weight: bad argument");
     VZ_CHECK_ARG(((uintptr_t)d_ptr & 15) == 0, "set_weight: '%s' must be 16-byte aligned", name);
+    RC(drop_decode_graph(e));
     e->w[name] = Weight{d_ptr, dtype, n_elems};
+    e->finalized = false;
+    return VZ_OK;
+}
+
+// forget a registered weight (the e4m3 copy / scales of a bf16 tensor that has been rewritten: finalize must not accept the stale ones)
+extern "C" int vz_engine_unset_weight(vz_engine* e, const char* name) {
+    VZ_CHECK_ARG(e && name, "unset_weight: bad argument");
+    RC(drop_decode_graph(e));
+    e->w.erase(name);
     e->finalized = false;
     return VZ_OK;
 }
@@ -422,6 +449,7 @@ extern "C" int vz_engine_finalize(vz_engine* e) {
 
 extern "C" int vz_engine_set_rope(vz_engine* e, const float* d_cos, const float* d_sin, int max_pos) {
     VZ_CHECK_ARG(e && d_cos && d_sin && max_pos > 0, "set_rope: bad argument");
+    RC(drop_decode_graph(e));
     e->cosT = d_cos; e->sinT = d_sin; e->rope_max = max_pos;
     return VZ_OK;
 }
@@ -655,6 +683,7 @@ static int ensure_gather(vz_engine* e, int rows, hipStream_t s) {
     const size_t local_off = ((size_t)e->tp * rows * e->Vp + 3) & ~(size_t)3;
     const size_t need = local_off + (size_t)rows * e->Vp;
     if (need > e->gather_floats) {
+        RC(drop_decode_graph(e));    // its all-gather / repack / lm_head nodes hold the old buffer and the old shard offset
         if (e->d_gather) { VZ_CHECK_HIP(hipStreamSynchronize(s)); VZ_CHECK_HIP(hipFree(e->d_gather)); e->d_gather = nullptr; }
         VZ_CHECK_HIP(hipMalloc((void**)&e->d_gather, need * sizeof(float)));
         e->gather_floats = need;
@@ -836,11 +865,12 @@ extern "C" int vz_llm_decode_begin(vz_engine* e, int B, const int* d_first_ids, 
         h[mb + b] = h_ctx_len[b];        // slot the next token is written to
         h[2 * mb + b] = h_ctx_len[b] + 1;  // keys visible to the next token
     }
-    RC(upload_ints(e, h.data(), h.size(), e->d_state + mb, s));   // [pos | slot | len | step=0]
+    h[3 * mb + 1] = e->samp_ctr0; h[3 * mb + 2] = (int)e->samp_seed[0]; h[3 * mb + 3] = (int)e->samp_seed[1];
+    RC(upload_ints(e, h.data(), h.size(), e->d_state + mb, s));   // [pos | slot | len | step = 0, draw counter, seed lo, seed hi]
     VZ_CHECK_HIP(hipMemcpyAsync(e->d_state, d_first_ids, B * sizeof(int), hipMemcpyDeviceToDevice, s));
     e->dec_B = B;
-    e->dec_len_max = 0;
-    for (int b = 0; b < B; ++b) e->dec_len_max = std::max(e->dec_len_max, h_ctx_len[b] + 1);
+    e->h_len.assign(B, 0); e->h_pos.assign(B, 0); e->h_parked.assign(B, 0);
+    for (int b = 0; b < B; ++b) { e->h_len[b] = h_ctx_len[b] + 1; e->h_pos[b] = h_next_pos[b]; e->h_parked[b] = h_ctx_len[b] == 0 && h_next_pos[b] == 0; }
     return VZ_OK;
 }
 
@@ -854,7 +884,7 @@ extern "C" int vz_llm_decode_set_row(vz_engine* e, int row, int token, int next_
     VZ_CHECK_ARG(ctx_len >= 0 && ctx_len < c.max_ctx && next_pos >= 0, "decode_set_row: ctx_len %d / pos %d outside [0,%d)", ctx_len, next_pos, c.max_ctx);
     const int mb = c.max_batch;
     const int h[4] = {token, next_pos, ctx_len, ctx_len + 1};     // cur | pos | slot | len: one int in each of the four state arrays
-    e->dec_len_max = std::max(e->dec_len_max, ctx_len + 1);
+    e->h_len[row] = ctx_len + 1; e->h_pos[row] = next_pos; e->h_parked[row] = ctx_len == 0 && next_pos == 0;
     hipStream_t s = (hipStream_t)stream;
     VZ_CHECK_ARG(e->h_pinned && e->h_pinned_ints >= 4, "decode_set_row: no staging buffer (vz_llm_decode_begin allocates it)");
     VZ_CHECK_HIP(hipStreamSynchronize(s));                        // previous use of the staging buffer has drained
@@ -934,10 +964,51 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
     }
     {
         ProfScope ps(e, K_OTHER, s);
-        RC(vz_launch_argmax(e->d_logits, B, c.vocab, cur, pos, slot, len, d_out_ids, out_stride, step, s));
+        if (e->samp_on)
+            RC(vz_launch_sample(e->d_logits, B, c.vocab, e->samp_temp, e->samp_top_k, e->samp_top_p, (const unsigned*)(step + 2), step + 1, 0, cur, pos,
+                                slot, len, d_out_ids, out_stride, step, c.max_ctx, e->rope_max, e->ring, e->ring_n, s));
+        else
+            RC(vz_launch_argmax(e->d_logits, B, c.vocab, cur, pos, slot, len, d_out_ids, out_stride, step, c.max_ctx, e->rope_max, e->ring, e->ring_n, s));
         RC(vz_launch_step_advance(step, s));
     }
     return VZ_OK;
+}
+
+// Sampling instead of argmax as the tail of every decode step (hf:generation/utils.py `_sample`, do_sample=True; see
+// sampling.hip): temperature > 0, top_k (0 = off; HF's default 50 is the caller's business), top_p (1 = off), a 64-bit seed and
+// the draw counter the NEXT vz_llm_decode_begin starts from (the caller drew token 0 from the prefill logits with vz_op_sample
+// and counter 0, so it passes 1).  enable = 0: greedy.
+extern "C" int vz_llm_decode_sampling(vz_engine* e, int enable, float temperature, int top_k, float top_p, unsigned long long seed,
+                                      int first_counter) {
+    VZ_CHECK_ARG(e, "decode_sampling: null engine");
+    if (!enable) { e->samp_on = 0; return VZ_OK; }
+    VZ_CHECK_ARG(temperature > 0.f && top_k >= 0 && top_p > 0.f && top_p <= 1.f && first_counter >= 0,
+                 "decode_sampling: temperature %g > 0, top_k %d >= 0, 0 < top_p %g <= 1 expected", (double)temperature, top_k, (double)top_p);
+    e->samp_on = 1; e->samp_temp = temperature; e->samp_top_k = top_k; e->samp_top_p = top_p;
+    e->samp_seed[0] = (unsigned)seed; e->samp_seed[1] = (unsigned)(seed >> 32); e->samp_ctr0 = first_counter;
+    return VZ_OK;
+}
+
+// Streamer / stopping-criteria path: besides d_out_ids every step's tail also writes its token to ring[row * ring_n + (draw
+// counter mod ring_n)], a DEVICE-VISIBLE HOST buffer (hipHostMalloc / pinned), so the host can keep a step or two in flight and
+// read token t as soon as the event recorded behind step t fires, without a device-to-host copy per token.  NULL = off.
+extern "C" int vz_llm_decode_ring(vz_engine* e, int* ring, int ring_n) {
+    VZ_CHECK_ARG(e && (!ring || ring_n >= 2), "decode_ring: ring_n >= 2 expected");
+    e->ring = ring; e->ring_n = ring ? ring_n : 0;
+    return VZ_OK;
+}
+
+// one draw per row of fp32 logits [rows, cols] with the same kernel (the first token of a sampled generation; tests)
+extern "C" int vz_op_sample(const float* d_logits, int rows, int cols, float temperature, int top_k, float top_p,
+                            unsigned long long seed, int counter, int* d_ids, vz_stream stream) {
+    static thread_local int* d_scratch = nullptr;        // [counter, seed lo, seed hi, -]
+    hipStream_t s = (hipStream_t)stream;
+    if (!d_scratch) VZ_CHECK_HIP(hipMalloc((void**)&d_scratch, 4 * sizeof(int)));
+    VZ_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)d_scratch, counter, 1, s));
+    VZ_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(d_scratch + 1), (int)(unsigned)seed, 1, s));
+    VZ_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(d_scratch + 2), (int)(unsigned)(seed >> 32), 1, s));
+    return vz_launch_sample(d_logits, rows, cols, temperature, top_k, top_p, (const unsigned*)(d_scratch + 1), d_scratch, 0, d_ids, nullptr,
+                            nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0, s);
 }
 
 extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d_logits_dbg, vz_stream stream) {
@@ -961,6 +1032,17 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     int* step = e->d_state + 4 * c.max_batch;
     VZ_CHECK_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
     VZ_CHECK_HIP(hipMemsetAsync(e->d_fcount, 0, (size_t)c.n_layers * 1024 * sizeof(unsigned), s));   // hand-off counters count from step 0
+    // Capacity (the cache append writes slot = len - 1 of the row, the rotary tables are read at pos): every live row must still fit
+    // after n steps.  Parked rows (continuous batching) are not checked: the step tail saturates their slot / position on the device.
+    int len_max = 0;
+    for (int b = 0; b < B; ++b) {
+        if (!e->h_parked[b]) {
+            VZ_CHECK_ARG(e->h_len[b] + n - 1 <= c.max_ctx, "decode_steps: row %d would reach %d keys, the cache holds max_ctx = %d", b, e->h_len[b] + n - 1, c.max_ctx);
+            VZ_CHECK_ARG(e->h_pos[b] + n - 1 < e->rope_max, "decode_steps: row %d would reach position %d, the rotary tables hold %d", b, e->h_pos[b] + n - 1, e->rope_max);
+        }
+        len_max = std::max(len_max, std::min(e->h_len[b], c.max_ctx));
+    }
+    e->dec_len_max = len_max;
     // Context splits of the decode attention = grid.x: a split takes >= 128 keys and workgroups that find nothing to do still cost
     // a dispatch slot each (measured: 4096 mostly idle workgroups = 59 us per layer at 16 rows), so the grid follows the longest
     // context these n steps can reach - known on the host - in coarse buckets (a new bucket = one re-capture of the graph).
@@ -972,16 +1054,22 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
         int ns = e->nsplit;
         for (int bk : buckets) if (bk >= need) { ns = std::min(bk, e->nsplit); break; }
         e->dec_nsplit = g_attn_nsplit > 0 ? g_attn_nsplit : ns;
-        e->dec_len_max += n;
+        for (int b = 0; b < B; ++b) {       // what the device-side state will be after these n steps (the tail saturates, so do we)
+            e->h_len[b] = std::min(e->h_len[b] + n, c.max_ctx);
+            e->h_pos[b] = std::min(e->h_pos[b] + n, e->rope_max - 1);
+        }
     }
     if (!use_graph) {
         for (int i = 0; i < n; ++i)
             RC(decode_step_launch(e, d_out_ids, n, d_logits_dbg ? d_logits_dbg + (size_t)i * B * c.vocab : nullptr, s));
         return VZ_OK;
     }
-    // Output pointer / stride and the workspace are kernel arguments frozen in the graph: re-capture when they change.
+    // Output pointer / stride, the workspace and the sampling parameters are kernel arguments frozen in the graph: re-capture when
+    // they change (seed and draw counter live in device memory and do not).
+    long samp_key[6] = {e->samp_on, e->samp_top_k, 0, 0, (long)(uintptr_t)e->ring, e->ring_n};
+    memcpy(&samp_key[2], &e->samp_temp, 4); memcpy(&samp_key[3], &e->samp_top_p, 4);
     if (!e->dec_graph || e->dec_graph_B != B || e->dec_graph_n != n || e->dec_graph_out != d_out_ids || e->dec_graph_arena != e->arena ||
-        e->dec_graph_nsplit != e->dec_nsplit || e->dec_graph_fuse != g_decode_fuse) {
+        e->dec_graph_nsplit != e->dec_nsplit || e->dec_graph_fuse != g_decode_fuse || memcmp(e->dec_graph_samp, samp_key, sizeof(samp_key)) != 0) {
         if (e->dec_graph) { hipGraphExecDestroy(e->dec_graph); e->dec_graph = nullptr; }
         hipGraph_t graph;
         if (!e->cap_stream) VZ_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
@@ -999,7 +1087,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
             for (int i = 0; i < n; ++i) RC(decode_step_launch(e, d_out_ids, n, nullptr, s));
             return VZ_OK;
         }
-        e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena; e->dec_graph_nsplit = e->dec_nsplit; e->dec_graph_fuse = g_decode_fuse;
+        e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena; e->dec_graph_nsplit = e->dec_nsplit; e->dec_graph_fuse = g_decode_fuse; memcpy(e->dec_graph_samp, samp_key, sizeof(samp_key));
     }
     for (int i = 0; i < n; ++i) VZ_CHECK_HIP(hipGraphLaunch(e->dec_graph, s));
     return VZ_OK;
@@ -1021,8 +1109,26 @@ extern "C" int vz_engine_async_error(vz_engine* e, int* err) {
     *err = 0;
     if (!e->d_ferr) return VZ_OK;
     VZ_CHECK_HIP(hipMemcpy(err, e->d_ferr, sizeof(int), hipMemcpyDeviceToHost));
-    if (*err) VZ_CHECK_HIP(hipMemset(e->d_ferr, 0, sizeof(int)));
+    if (*err) {
+        VZ_CHECK_HIP(hipMemset(e->d_ferr, 0, sizeof(int)));
+        // the hand-off words / tickets that made a wait expire are in an unknown state: start the next launch from zero
+        VZ_CHECK_HIP(hipMemset(e->d_fcount, 0, (size_t)e->c.n_layers * 1024 * sizeof(unsigned)));
+        int dummy = 0;
+        RC(vz_gemm256_async_error(e->last_stream, &dummy, true));
+    }
     return VZ_OK;
+}
+
+// the same word for op-level launches on `stream` (vz_op_linear* taking the stream-K path): blocking read + clear
+extern "C" int vz_op_async_error(vz_stream stream, int* err) {
+    VZ_CHECK_ARG(err, "op_async_error: null argument");
+    return vz_gemm256_async_error((hipStream_t)stream, err, false);
+}
+
+// TEST HOOK: overwrite the {arrive, ready} pair of stream-K remainder tile `tile` on `stream` (tests/test_ops_gpu.py drives an
+// expired fix-up wait with it: the launch must end, raise VZ_ASYNC_STREAMK and write NaN, never a sum of stale slots)
+extern "C" int vz_test_corrupt_streamk(vz_stream stream, int tile, int arrive, int ready) {
+    return vz_gemm256_corrupt_tickets((hipStream_t)stream, tile, arrive, ready);
 }
 
 extern int g_gemm256_streamk, g_gemm256_skew, g_gemm256_stamps, g_gemm256_drain;

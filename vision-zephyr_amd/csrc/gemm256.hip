@@ -34,6 +34,10 @@
 //     slot (write-through stores), the last arriver adds them (in slice order when there are more than two, so results
 //     do not depend on arrival order) and runs the epilogue.  The only wait is the finisher's for slices whose owners
 //     have already arrived and are storing (bounded; no workgroup waits for one that may not be running).
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "vz_common.h"
 
 namespace {
@@ -54,6 +58,7 @@ struct Gemm256Params {
     // tiles are cut into sk_wgs ranges of units_per_wg
     int n_full, n_rem, sk_wgs, units_per_wg, sk_skew;
     float* ws; int* tickets;
+    int* err;                // async error word: a bounded wait of the stream-K fix-up that expired raises VZ_ASYNC_STREAMK here
     long long* stamps;   // profiling only (vz_tune_set(6, 1)): s_memrealtime at phase boundaries, 16 per workgroup
 };
 
@@ -448,8 +453,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
             unsigned* arrive = (unsigned*)p.tickets + 2 * tr;
             unsigned* ready = arrive + 1;
             int* flag = (int*)smem;     // the ring is idle here
-            if (tid == 0)
-                *flag = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nseg - 1);
+            if (tid == 0) {
+                const unsigned before = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = before == (unsigned)(nseg - 1);
+                // more arrivals than the tile has slices: the pair was not zero when this launch began (see the finisher's wait)
+                if (before >= (unsigned)nseg && p.err) __hip_atomic_store(p.err, VZ_ASYNC_STREAMK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __syncthreads();
             finish = __builtin_amdgcn_readfirstlane(*flag) != 0;
             if (!finish || nseg > 2) {       // (with more than two slices the finisher parks its own too: fixed summation order)
@@ -462,14 +471,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
             if (finish) {
                 if (tid == 0) {
                     // bounded (guide section 5.6 "bound every spin"): the slices waited for are already past their main loop, so the
-                    // wait is one 256 KiB write; a count that never arrives (or overshoots) must not hang the device
-                    for (int spins = 0; __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(nseg - 1) && spins < (1 << 22); ++spins)
+                    // wait is one 256 KiB write.  A count that never arrives means the {arrive, ready} pair of this tile was not what
+                    // this launch assumed (another launch on the same workspace at the same time, or counters left by a launch that
+                    // was torn down): the finisher then raises the async error word, leaves BOTH counters as they are (a late slice
+                    // must not find a freshly zeroed `ready` to bump - that would hand the next launch a count for slots nobody has
+                    // written) and poisons the tile with NaN instead of summing stale slots.  The host resets the counters when it
+                    // reads the error (vz_engine_async_error / vz_op_async_error).
+                    int spins = 0;
+                    while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(nseg - 1) && spins < (1 << 22)) {
                         __builtin_amdgcn_s_sleep(4);
-                    __hip_atomic_store(ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // both counters ready for
-                    __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the next launch
+                        ++spins;
+                    }
+                    const bool ok = spins < (1 << 22);
+                    if (ok) {
+                        __hip_atomic_store(ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // both counters ready for
+                        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the next launch
+                    } else if (p.err) {
+                        __hip_atomic_store(p.err, VZ_ASYNC_STREAMK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    flag[1] = ok ? 1 : 0;
                 }
                 __syncthreads();        // everyone loads behind the lane that saw the count
-                if (nseg == 2) {
+                if (__builtin_amdgcn_readfirstlane(flag[1]) == 0) {
+                    VZ_ACC_FOR_EACH({ (void)i_; a_ = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")}; })
+                } else if (nseg == 2) {
                     const float* other = slots + (size_t)(seg ^ 1) * TILE_FLOATS;
                     VZ_ACC_ADD_FROM(other)
                 } else {        // fixed slice order: the sum does not depend on who arrived last
@@ -521,10 +546,35 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
 
 long long* g_stamps;         // 16 stamps per workgroup of the last launch (profiling knob 6)
 int g_stamp_wgs;
-float* g_ws;                 // stream-K workspace: process-wide, one GEMM at a time per process (launches are stream-ordered)
-size_t g_ws_bytes;
-int* g_tickets;
 int g_num_cu;
+
+// Stream-K state = {fp32 slots, {arrive, ready} per remainder tile, async error word}.  Launches that share it must be ordered,
+// so there is one per (device, stream): two engines, two streams or two devices in one process never meet on one set of
+// tickets (round 1 had ONE process-wide set - see DESIGN.md section 5b).  Allocated on first use of a stream by a launch that
+// takes the stream-K path, never inside a stream capture (the capturing launcher gets whole tiles only).
+struct SkState { float* ws = nullptr; int* tickets = nullptr; int* err = nullptr; size_t ws_bytes = 0; int n_tickets = 0; };
+std::mutex g_sk_mu;
+std::map<std::pair<int, hipStream_t>, SkState> g_sk;
+
+int sk_state_for(hipStream_t s, SkState** out) {
+    int dev = 0;
+    VZ_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    SkState& st = g_sk[{dev, s}];
+    if (!st.ws) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone) { *out = nullptr; return VZ_OK; }       // no allocation inside a capture
+        st.ws_bytes = (size_t)2 * g_num_cu * TILE_FLOATS * sizeof(float);               // <= P + n_rem slots are ever in use
+        st.n_tickets = 2 * g_num_cu;                                                    // {arrive, ready} per remainder tile
+        VZ_CHECK_HIP(hipMalloc((void**)&st.ws, st.ws_bytes));
+        VZ_CHECK_HIP(hipMalloc((void**)&st.tickets, (size_t)(st.n_tickets + 4) * sizeof(int)));
+        VZ_CHECK_HIP(hipMemset(st.tickets, 0, (size_t)(st.n_tickets + 4) * sizeof(int)));
+        st.err = st.tickets + st.n_tickets;
+    }
+    *out = &st;
+    return VZ_OK;
+}
 
 }  // namespace
 
@@ -540,10 +590,6 @@ int vz_init_gemm256_kernel() {
     int dev = 0;
     VZ_CHECK_HIP(hipGetDevice(&dev));
     VZ_CHECK_HIP(hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    g_ws_bytes = (size_t)2 * g_num_cu * TILE_FLOATS * sizeof(float);       // <= P + n_rem slots are ever in use
-    VZ_CHECK_HIP(hipMalloc((void**)&g_ws, g_ws_bytes));
-    VZ_CHECK_HIP(hipMalloc((void**)&g_tickets, (size_t)2 * g_num_cu * sizeof(int)));      // {arrive, ready} per remainder tile
-    VZ_CHECK_HIP(hipMemset(g_tickets, 0, (size_t)2 * g_num_cu * sizeof(int)));
     VZ_CHECK_HIP(hipMalloc((void**)&g_stamps, (size_t)4096 * 16 * sizeof(long long)));
     VZ_CHECK_HIP(hipDeviceSynchronize());
     done = true;
@@ -563,7 +609,7 @@ int vz_launch_gemm256(const LinearArgs& a, hipStream_t s) {
     p.tiles_n = (a.N + 255) / 256;
     const int T = p.tiles_m * p.tiles_n, P = g_num_cu, nk = a.K >> 6;
     p.n_full = T; p.n_rem = 0; p.sk_wgs = 0; p.units_per_wg = 1; p.sk_skew = 0;
-    p.ws = g_ws; p.tickets = g_tickets;
+    p.ws = nullptr; p.tickets = nullptr; p.err = nullptr;
     const int rem = T % P;
     // a last round that fills at most half of the CUs is cut along K instead.  Measured (S=2048): down-proj (128 tiles,
     // K=14336) 250 -> 190 us, Q-Former cross-attention K/V (384 tiles) 227 -> 214 us; a fuller tail (QKV, 192 tiles) does
@@ -575,9 +621,12 @@ int vz_launch_gemm256(const LinearArgs& a, hipStream_t s) {
         if (wgs >= 1) {
             const int U = (int)((units + wgs - 1) / wgs);
             wgs = (units + U - 1) / U;
-            if ((size_t)(wgs + rem) * TILE_FLOATS * sizeof(float) <= g_ws_bytes) {
+            SkState* st = nullptr;
+            { int r = sk_state_for(s, &st); if (r) return r; }
+            if (st && (size_t)(wgs + rem) * TILE_FLOATS * sizeof(float) <= st->ws_bytes && 2 * rem <= st->n_tickets) {
                 p.n_full = T - rem; p.n_rem = rem; p.sk_wgs = (int)wgs; p.units_per_wg = U;
                 p.sk_skew = U >= 24 ? g_gemm256_skew : 0;
+                p.ws = st->ws; p.tickets = st->tickets; p.err = a.err ? a.err : st->err;
             }
         }
     }
@@ -598,5 +647,38 @@ int vz_gemm256_read_stamps(long long* host, int max_wgs, int* n_wgs) {
     const int n = g_stamp_wgs < max_wgs ? g_stamp_wgs : max_wgs;
     if (n > 0) VZ_CHECK_HIP(hipMemcpy(host, g_stamps, (size_t)n * 16 * sizeof(long long), hipMemcpyDeviceToHost));
     *n_wgs = n;
+    return VZ_OK;
+}
+
+// Async error of the stream-K fix-up on `s` (op-level launches; an engine passes its own word through LinearArgs.err and reports
+// it through vz_engine_async_error).  Blocking: waits for the stream, reads the word, and when it is set clears it AND the
+// tickets of that stream so the next launch starts from clean counters.
+int vz_gemm256_async_error(hipStream_t s, int* err, bool reset_only) {
+    *err = 0;
+    int dev = 0;
+    VZ_CHECK_HIP(hipGetDevice(&dev));
+    SkState st;
+    {
+        std::lock_guard<std::mutex> lk(g_sk_mu);
+        auto it = g_sk.find({dev, s});
+        if (it == g_sk.end() || !it->second.ws) return VZ_OK;
+        st = it->second;
+    }
+    VZ_CHECK_HIP(hipStreamSynchronize(s));
+    if (!reset_only) VZ_CHECK_HIP(hipMemcpy(err, st.err, sizeof(int), hipMemcpyDeviceToHost));
+    if (*err || reset_only) VZ_CHECK_HIP(hipMemset(st.tickets, 0, (size_t)(st.n_tickets + 4) * sizeof(int)));
+    return VZ_OK;
+}
+
+// test hook: leave the {arrive, ready} pair of remainder tile `tr` on stream `s` in a state no launch can complete from
+int vz_gemm256_corrupt_tickets(hipStream_t s, int tr, int arrive, int ready) {
+    int dev = 0;
+    VZ_CHECK_HIP(hipGetDevice(&dev));
+    SkState* st = nullptr;
+    { int r = sk_state_for(s, &st); if (r) return r; }
+    VZ_CHECK_ARG(st && tr >= 0 && 2 * tr + 1 < st->n_tickets, "corrupt_tickets: bad tile");
+    const int v[2] = {arrive, ready};
+    VZ_CHECK_HIP(hipStreamSynchronize(s));
+    VZ_CHECK_HIP(hipMemcpy(st->tickets + 2 * tr, v, sizeof(v), hipMemcpyHostToDevice));
     return VZ_OK;
 }

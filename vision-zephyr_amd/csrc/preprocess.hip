@@ -98,8 +98,67 @@ int grid_for(long total) {
     long b = (total + 255) / 256;
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
+// ---- ViP "point" overlay (second half) ---------------------------------------------------------
+// `image_blending(shape="point")` (ref:vis_zephyr/model/vip_processor/conversation_generator.py:143-153,170-175 ->
+// ref:vis_zephyr/model/vip_processor/shape_draw.py:130-138) = Pillow's filled ellipse on a transparent RGBA canvas +
+// Image.alpha_composite + convert("RGB").  Both are integer arithmetic (Pillow src/libImaging/Draw.c ellipseNew / quarter_next,
+// src/libImaging/AlphaComposite.c), restated in oracle/vip_oracle.py and pinned against Pillow; reproduced here bit for bit.
+// One launch per point, over the ellipse's bounding box: lane 0 of every workgroup walks the quarter ellipse in doubled
+// coordinates (<= (a + b) / 2 + 1 error-minimising steps, int64) into an LDS table r[(Y - b % 2) / 2] = half-width of scanline
+// Y; then a pixel (x, y) is inside iff (a - r) >> 1 <= x - x0 <= (a + r) >> 1 with Y = |2 (y - y0) - b|, and is replaced by
+// the composite of the constant colour over it: t = src * (sa * 128) + dst * ((255 - sa) * 128) + (0x80 << 7);
+// out = ((((t >> 8) + t) >> 8) >> 7).
+constexpr int VIP_MAX_ROWS = 2048;        // doubled-scanline table: ellipses up to 4094 pixels tall
+
+__global__ __launch_bounds__(256) void vip_point_kernel(unsigned char* __restrict__ img, int h, int w, int x0, int y0, int a, int b,
+                                                        unsigned rgba) {
+    __shared__ int r_of[VIP_MAX_ROWS];
+    if (threadIdx.x == 0) {
+        const long long a2 = (long long)a * a, b2 = (long long)b * b, a2b2 = a2 * b2;
+        auto delta = [&](long long x, long long y) { const long long d = a2 * y * y + b2 * x * x - a2b2; return d < 0 ? -d : d; };
+        int cx = a, cy = b & 1;
+        const int ex = a & 1, ey = b;
+        int last_row = -1;
+        while (true) {
+            const int row = (cy - (b & 1)) >> 1;
+            if (row != last_row) { r_of[row] = cx; last_row = row; }       // the FIRST point of a scanline is its right end
+            if (cx == ex && cy == ey) break;
+            int nx = cx, ny = cy + 2;
+            long long nd = delta(nx, ny);
+            if (nx > 1) {
+                long long d = delta(cx - 2, cy + 2);
+                if (nd > d) { nx = cx - 2; ny = cy + 2; nd = d; }
+                d = delta(cx - 2, cy);
+                if (nd > d) { nx = cx - 2; ny = cy; }
+            }
+            cx = nx; cy = ny;
+        }
+    }
+    __syncthreads();
+    const unsigned sr = rgba & 255, sg = (rgba >> 8) & 255, sb = (rgba >> 16) & 255, sa = rgba >> 24;
+    const unsigned c1 = sa * 128u, c2 = (255u - sa) * 128u;
+    const int bw = (a >> 1) + 1 + ((a & 1) ? 1 : 0), bh = b + 1;         // pixel box [x0, x0 + a] x [y0, y0 + b] (spans end at (a + r) >> 1 <= a)
+    const int cols = a + 1;
+    (void)bw;
+    const long total = (long)cols * bh;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int t = (int)(i / cols), dx = (int)(i - (long)t * cols);
+        const int y = y0 + t, x = x0 + dx;
+        if (y < 0 || y >= h || x < 0 || x >= w) continue;
+        int Y = 2 * t - b;
+        Y = Y < 0 ? -Y : Y;
+        const int r = r_of[(Y - (b & 1)) >> 1];
+        if (dx < ((a - r) >> 1) || dx > ((a + r) >> 1)) continue;
+        unsigned char* p = img + ((size_t)y * w + x) * 3;
+        unsigned tr = sr * c1 + p[0] * c2 + (0x80u << 7), tg = sg * c1 + p[1] * c2 + (0x80u << 7), tb = sb * c1 + p[2] * c2 + (0x80u << 7);
+        p[0] = (unsigned char)((((tr >> 8) + tr) >> 8) >> 7);
+        p[1] = (unsigned char)((((tg >> 8) + tg) >> 8) >> 7);
+        p[2] = (unsigned char)((((tb >> 8) + tb) >> 8) >> 7);
+    }
+}
 
 }  // namespace
+
 
 extern "C" int vz_op_resample_u8(const void* d_src, int h, int w, void* d_tmp, void* d_dst, int h2, int w2, const int* d_xbounds,
                                  const int* d_xcoefs, int kx, const int* d_ybounds, const int* d_ycoefs, int ky, vz_stream stream) {
@@ -139,6 +198,17 @@ extern "C" int vz_op_anyres_tiles(const void* d_global, const void* d_resized, i
     hipLaunchKernelGGL(anyres_tiles_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)d_global,
                        (const unsigned char*)d_resized, nh, nw, paste_x, paste_y, grid_w, grid_h, side, (const unsigned short*)d_lut,
                        (unsigned short*)d_out);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
+extern "C" int vz_op_vip_point(void* d_image, int h, int w, int x0, int y0, int x1, int y1, unsigned rgba, vz_stream stream) {
+    VZ_CHECK_ARG(d_image && h > 0 && w > 0, "vip_point: bad argument");
+    const int a = x1 - x0, b = y1 - y0;
+    if (a < 0 || b < 0 || (rgba >> 24) == 0) return VZ_OK;          // Pillow draws nothing / alpha 0 composites to the image itself
+    VZ_CHECK_ARG(b / 2 + 1 <= VIP_MAX_ROWS && a <= 1 << 20, "vip_point: ellipse %d x %d too large", a, b);
+    const long total = (long)(a + 1) * (b + 1);
+    hipLaunchKernelGGL(vip_point_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (unsigned char*)d_image, h, w, x0, y0, a, b, rgba);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }

@@ -125,6 +125,8 @@ struct LinearArgs {
     // Q-Former linears: there a row's result must not depend on how many rows sit beside it (the tile GEMM's split-K is a
     // function of N and K only; tests/test_stages_gpu.py::test_qformer), and 32 / 64 / 96 rows must all take the same kernel.
     bool wide_ok = true;
+    // async error word of the caller (an engine's); nullptr = the launch stream's own (vz_op_async_error)
+    int* err = nullptr;
 };
 int vz_launch_gemm(const LinearArgs& a, hipStream_t s);
 int vz_linear_check_common(const LinearArgs& a);
@@ -154,6 +156,8 @@ int vz_launch_gemv(const LinearArgs& a, hipStream_t s);
 int vz_launch_gemm128(const LinearArgs& a, hipStream_t s);
 int vz_launch_gemm256(const LinearArgs& a, hipStream_t s);
 int vz_init_gemm256_kernel();
+int vz_gemm256_async_error(hipStream_t s, int* err, bool reset_only);
+int vz_gemm256_corrupt_tickets(hipStream_t s, int tr, int arrive, int ready);
 void vz_set_gemm_choice(int v);
 void vz_set_splitk_mode(int v);   // 0 auto, 1 force 128x128, 2 force 256x256
 int vz_launch_linear(const LinearArgs& a, hipStream_t s);  // picks by M
@@ -233,7 +237,10 @@ int vz_launch_clip_assemble(const bf16_t* patch_out, const bf16_t* cls, const bf
 int vz_launch_fusion(const bf16_t* hs_base, long layer_stride, int first_layer, int groups, int per_group, int T,
                      int tokens, int C, int skip, bf16_t* out, hipStream_t s);
 int vz_launch_argmax(const float* logits, int rows, int cols, int* ids, int* pos, int* slot, int* len, int* out_ids,
-                     int out_stride, const int* step, hipStream_t s);
+                     int out_stride, const int* step, int max_ctx, int rope_max, int* ring, int ring_n, hipStream_t s);
+int vz_launch_sample(const float* logits, int rows, int cols, float temperature, int top_k, float top_p, const unsigned* seed,
+                     const int* ctr, int ctr_add, int* ids, int* pos, int* slot, int* len, int* out_ids, int out_stride,
+                     const int* step, int max_ctx, int rope_max, int* ring, int ring_n, hipStream_t s);
 // set dynamic-LDS limits of every kernel up front (never inside a stream capture)
 int vz_init_gemm_kernels();
 int vz_init_attention_kernels();

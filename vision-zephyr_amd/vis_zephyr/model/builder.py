@@ -3,7 +3,7 @@
 
 The three load modes of the reference are kept (LoRA adapter + base, base + mm_projector.bin, consolidated directory).
 Weights are streamed file by file straight into the engine's HBM layout (bf16; the reference forces fp16,
-builder.py:45); `mm_vision_tower` must resolve to a local directory here - there is no network on the box."""
+builder.py:45); hub ids (`model_path`, `model_base`, `mm_vision_tower`) resolve through the local HuggingFace cache (`local_files_only`) - there is no network on the box."""
 from __future__ import annotations
 
 import json
@@ -40,6 +40,11 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit: bool = 
         warnings.warn("There is `lora` in model name but no `model_base` is provided. If you are loading a LoRA model, "
                       "please provide the `model_base` argument.")
         lora = False
+    # hub ids (script/run_cli.sh passes HuggingFaceH4/zephyr-7b-beta; the shipped config names openai/clip-vit-large-patch14-336)
+    # resolve through the LOCAL HF cache before anything raises
+    model_path = W.resolve_hub_path(model_path, "model_path")
+    if model_base is not None:
+        model_base = W.resolve_hub_path(model_base, "model_base")
     tokenizer = AutoTokenizer.from_pretrained(model_base if model_base is not None else model_path, use_fast=False)
     config = _load_config(model_path)
 
@@ -50,10 +55,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit: bool = 
         tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
     config.vocab_size = len(tokenizer)                 # the engine is built at the resized vocabulary (32001)
 
-    clip_dir = getattr(config, "mm_vision_tower", None)
-    if clip_dir is None or not os.path.isdir(clip_dir):
-        raise FileNotFoundError(f"mm_vision_tower = {clip_dir!r} must be a local directory holding the CLIP ViT-L/14-336 "
-                                "weights and preprocessor_config.json (no network access)")
+    clip_dir = W.resolve_hub_path(getattr(config, "mm_vision_tower", None), "mm_vision_tower")
     dev = "cuda:0" if device == "cuda" else device
     model = VisZephyrForCausalLM(config, device=dev, max_ctx=kwargs.pop("max_ctx", 4096), weight_fp8=bool(load_8bit))
     model.load_state_dict_stream(W.resize_vocab(W.iter_reference_checkpoint(model_path, model_base, clip_dir, lora=lora),

@@ -57,6 +57,7 @@ class _Embedding:
         self._owner = owner
 
     def __call__(self, ids):
+        self._owner._ensure_ready()
         return self._owner.engine.embed_tokens(ids)
 
     @property
@@ -115,8 +116,12 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         self.dtype = torch.bfloat16
         self.model = VisZephyrModel(config, self)
         self.lm_head = _LMHead(self)
+        # hf:generation/configuration_utils.py (pinned 4.52.4) defaults that the reference's callers rely on without naming them:
+        # do_sample=True with only `temperature` passed (ref:vis_zephyr/serve/cli.py:171-182) still goes through TopKLogitsWarper(50)
         self.generation_config = SimpleNamespace(eos_token_id=getattr(config, "eos_token_id", 2),
-                                                 pad_token_id=getattr(config, "pad_token_id", None))
+                                                 pad_token_id=getattr(config, "pad_token_id", None), top_k=50, top_p=1.0,
+                                                 temperature=1.0)
+        self._ring = None
 
     # ---- construction helpers -------------------------------------------------------------------
     @classmethod
@@ -127,6 +132,49 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         if m.get_vision_tower() is not None:
             m.get_vision_tower().is_loaded = True
         return m
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, low_cpu_mem_usage=True, torch_dtype=None,
+                        device_map=None, device="cuda:0", **kw):
+        """HF's entry point with the reference's usage (ref:vis_zephyr/model/builder.py:108-129): a directory or a hub id
+        resolved through the LOCAL cache; `config=` overrides the directory's config.json (the base + mm_projector.bin mode
+        passes the finetuned config while the weights come from the Zephyr base).  Streams every weight file of the directory
+        into the engine; what the directory lacks (mm_projector.bin arrives through `load_state_dict`, the CLIP tower through
+        `get_vision_tower().load_model()`) is completed later - the engine is finalized at first use."""
+        import json
+        import os
+        from vz_hip import weights as W
+        path = W.resolve_hub_path(pretrained_model_name_or_path, "pretrained_model_name_or_path")
+        if config is None:
+            with open(os.path.join(path, "config.json")) as f:
+                d = json.load(f)
+            for k in ("model_type", "architectures", "transformers_version"):
+                d.pop(k, None)
+            config = VisZephyrConfig(**d)
+        if isinstance(device_map, dict) and "" in device_map:          # ref builder.py:29-31: device_map = {"": device}
+            device = device_map[""]
+        dev = "cuda:0" if str(device) == "cuda" else device
+        engine_kw = {k: kw.pop(k) for k in ("max_batch", "max_ctx", "max_tiles", "max_text", "tp_size", "tp_rank", "weight_fp8") if k in kw}
+        model = cls(config, device=dev, **engine_kw)
+        for name, t in W.iter_backbone(path):
+            model.engine.add_weight(name, t)
+        return model
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """`model.load_state_dict(mm_projector_weights, strict=False)` (ref builder.py:121-123): reference-named tensors into
+        the engine.  Returns HF's (missing_keys, unexpected_keys) shape with the keys the engine does not take."""
+        from vz_hip import weights as W
+        unexpected = [k for k, v in W.normalize_keys(state_dict.items()) if not self.engine.add_weight(k, v)]
+        if strict and unexpected:
+            raise RuntimeError(f"Unexpected key(s) in state_dict: {unexpected[:8]}")
+        return SimpleNamespace(missing_keys=[], unexpected_keys=unexpected)
+
+    def _ensure_ready(self):
+        """finalize lazily: weights may arrive in several steps (from_pretrained, load_state_dict, the tower's load_model);
+        the C side names the first missing tensor if something never arrived."""
+        if not self.engine.ready:
+            self.engine.finalize()
+            self.engine.init_comm()
 
     def load_state_dict_stream(self, named_tensors):
         """feed (reference key, tensor) pairs - e.g. safetensors shards + mm_projector.bin
@@ -162,6 +210,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
                 inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
                 output_hidden_states=None, images=None, images_size=None, return_dict=None, **kwargs):
+        self._ensure_ready()
         if past_key_values is not None:
             raise NotImplementedError("forward() with an external past_key_values: use generate(); the cache is "
                                       "engine-owned")
@@ -226,6 +275,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
     # ---- generate (a3, a13) -------------------------------------------------------------------------
     @torch.no_grad()
     def generate(self, input_ids: Optional[torch.Tensor] = None, images=None, images_size=None, **kwargs):
+        self._ensure_ready()
         position_ids = kwargs.pop("position_ids", None)
         attention_mask = kwargs.pop("attention_mask", None)
         if "inputs_embeds" in kwargs:
@@ -241,9 +291,9 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
 
     def _generate_from_embeds(self, inputs_embeds, attention_mask, position_ids, max_new_tokens: Optional[int] = None,
                               max_length: Optional[int] = None, do_sample: bool = False, temperature: float = 1.0,
-                              top_p: Optional[float] = None, top_k: Optional[int] = None, eos_token_id=None,
+                              top_p: Optional[float] = None, top_k: Optional[int] = -1, eos_token_id=None,
                               pad_token_id=None, streamer=None, stopping_criteria=None, use_cache: bool = True,
-                              num_beams: int = 1, generator: Optional[torch.Generator] = None,
+                              num_beams: int = 1, generator: Optional[torch.Generator] = None, seed: Optional[int] = None,
                               sync_every: int = 16, timing: Optional[dict] = None, **unused):
         if num_beams != 1:
             raise NotImplementedError("beam search is not on the reference's inference path (cli/eval use sampling/greedy)")
@@ -258,6 +308,13 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         if pad_token_id is None:
             pad_token_id = min(eos) if eos else 0
         greedy = (not do_sample) or temperature is None or temperature <= 0
+        if top_k == -1:                      # not passed: HF's generation-config default (50); None / 0 = no top-k filter
+            top_k = self.generation_config.top_k
+        if top_p is None:
+            top_p = self.generation_config.top_p
+        if seed is None:                     # one 64-bit seed per generate call: from the caller's generator, else from torch's global one
+            seed = 0 if greedy else int(torch.randint(0, 2 ** 62, (1,), generator=generator,
+                                                      device=generator.device if generator is not None else "cpu").item())
         inputs_embeds, attention_mask, position_ids, _ = self._to_right_padded(inputs_embeds, attention_mask, position_ids)
         seqlens = self._seqlens(attention_mask, Bsz, S)
         if Bsz > 1 and greedy and streamer is None and stopping_criteria is None:
@@ -267,7 +324,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
             outs.append(self._generate_one(inputs_embeds[b:b + 1, :seqlens[b]],
                                            None if position_ids is None else position_ids[b:b + 1, :seqlens[b]],
                                            max_new_tokens, greedy, temperature, top_p, top_k, eos, streamer if Bsz == 1 else None,
-                                           stopping_criteria, generator, sync_every, timing))
+                                           stopping_criteria, seed + b, sync_every, timing))
         n = max(len(o) for o in outs)
         res = torch.full((Bsz, n), pad_token_id, dtype=torch.long, device=self.device)
         for b, o in enumerate(outs):
@@ -333,6 +390,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         the next host sync (every `sync_every` steps), the other rows keep decoding.  Yields `(index, LongTensor[n_new])` in
         completion order; every sequence gets exactly the tokens `generate` gives it alone (rows are independent)."""
         from vz_hip import binding as B
+        self._ensure_ready()
         eng = self.engine
         if eos_token_id is None:
             eos_token_id = self.generation_config.eos_token_id
@@ -387,57 +445,85 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
                     eng.decode_set_row(r, 0, 0, 0)                       # park until the next request arrives
                     slots[r] = None
 
+    def _token_ring(self, n: int = 8) -> torch.Tensor:
+        """pinned host buffer the step tails write their tokens to (device-visible: hipHostMalloc memory is mapped)."""
+        if self._ring is None or self._ring.numel() != n:
+            self._ring = torch.zeros(n, dtype=torch.int32).pin_memory()
+        return self._ring
+
     def _generate_one(self, embeds, position_ids, max_new, greedy, temperature, top_p, top_k, eos, streamer,
-                      stopping_criteria, generator, sync_every, timing=None) -> List[int]:
+                      stopping_criteria, seed, sync_every, timing=None) -> List[int]:
+        """One sequence.  The first token comes from the prefill logits (argmax / one draw of the device sampler with counter 0),
+        every later one from a replay of the per-token hipGraph whose tail is the argmax or the sampling kernel - also on the path
+        `script/run_cli.sh` takes (streamer + stopping criteria + do_sample, ref:vis_zephyr/serve/cli.py:155-182): there the host
+        keeps ONE step in flight and reads token t from a host-visible ring when the event behind step t fires, so the callbacks
+        of token t run under step t+1 and no logits ever travel."""
+        from vz_hip import binding as B
         eng = self.engine
         S = embeds.shape[1]
         if S + max_new > eng.max_ctx:
             raise ValueError(f"prompt ({S}) + max_new_tokens ({max_new}) exceeds the engine's max_ctx ({eng.max_ctx})")
         _, last = eng.prefill(embeds, [S], position_ids, all_logits=False, last_logits=True)
         next_pos = S if position_ids is None else int(position_ids[0, -1]) + 1
-        per_token = streamer is not None or stopping_criteria is not None or not greedy
+        per_token = streamer is not None or stopping_criteria is not None
         out: List[int] = []
-
-        def pick(logits_row: torch.Tensor) -> int:
-            if greedy:
-                from vz_hip import binding as B
-                return int(B.argmax(logits_row.view(1, -1).contiguous())[0])
-            return _sample(logits_row, temperature, top_p, top_k, generator)
-
         if streamer is not None:
             # HF hands the (empty, since generation starts from embeddings) prompt ids to the streamer first;
             # TextStreamer(skip_prompt=True) swallows exactly one put() as "the prompt"
             streamer.put(torch.empty((1, 0), dtype=torch.long))
-        tok = pick(last[0])          # int(): the host holds the first token here
+        first = B.argmax(last) if greedy else B.sample(last, temperature, top_k, top_p, seed, 0)
+        tok = int(first[0])          # int(): the host holds the first token here
         if timing is not None:
             import time
             timing["t_first_token"] = time.perf_counter()
         out.append(tok)
-        if self._emit(out, streamer, stopping_criteria, last, eos):
+        if self._emit(out, streamer, stopping_criteria, None, eos) or max_new <= 1:
             return self._finish(out, streamer)
-        if per_token:
-            while len(out) < max_new:
-                eng.decode_begin(torch.tensor([out[-1]], dtype=torch.int32), [next_pos + len(out) - 1], [S + len(out) - 1])
-                ids, lg = eng.decode_steps(1, return_logits=True)
-                tok = int(ids[0, 0]) if greedy else pick(lg[0, 0])
-                out.append(tok)
-                if self._emit(out, streamer, stopping_criteria, lg[0], eos):
-                    break
-            return self._finish(out, streamer)
-        # greedy without host callbacks: steps are enqueued back to back, the host looks at the ids every
-        # `sync_every` tokens only to honour eos
-        eng.decode_begin(torch.tensor([tok], dtype=torch.int32), [next_pos], [S])
-        remaining = max_new - 1
-        while remaining > 0:
-            n = min(sync_every, remaining) if eos else remaining
-            ids = eng.decode_steps(n)[0].tolist()
-            eng.check_async()                 # a bounded device-side hand-off wait that expired = invalid ids: fail loudly
-            remaining -= n
-            for t in ids:
-                out.append(int(t))
-                if int(t) in eos:
-                    return out
-        return out
+        eng.set_sampling(not greedy, temperature if not greedy else 1.0, top_k, top_p, seed, first_counter=1)
+        try:
+            if per_token:
+                ring = self._token_ring()
+                R = ring.numel()
+                eng.set_ring(ring)
+                eng.decode_begin(first, [next_pos], [S])
+                dev_out = torch.empty(1, 1, dtype=torch.int32, device=self.device)
+                events = {}
+
+                def launch(t):               # step producing generated token index t (draw counter t)
+                    eng.decode_steps(1, out=dev_out)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    events[t] = ev
+
+                launch(1)
+                t = 1
+                while True:
+                    if t + 1 < max_new:
+                        launch(t + 1)        # speculative: its cache slot / ring slot are simply ignored if token t stops the sequence
+                    events.pop(t).synchronize()
+                    out.append(int(ring[t % R]))
+                    if self._emit(out, streamer, stopping_criteria, None, eos) or len(out) >= max_new:
+                        break
+                    t += 1
+                torch.cuda.current_stream(self.device).synchronize()      # a speculative step may still be running
+                eng.check_async()
+                return self._finish(out, streamer)
+            # no host callbacks: steps are enqueued back to back, the host looks at the ids every `sync_every` tokens only to honour eos
+            eng.decode_begin(first, [next_pos], [S])
+            remaining = max_new - 1
+            while remaining > 0:
+                n = min(sync_every, remaining) if eos else remaining
+                ids = eng.decode_steps(n)[0].tolist()
+                eng.check_async()                 # a bounded device-side wait that expired = invalid ids: fail loudly
+                remaining -= n
+                for t in ids:
+                    out.append(int(t))
+                    if int(t) in eos:
+                        return out
+            return out
+        finally:
+            eng.set_sampling(False)
+            eng.set_ring(None)
 
     def _emit(self, out, streamer, stopping_criteria, scores, eos) -> bool:
         """per-token host callbacks; returns True when generation must stop."""
@@ -471,18 +557,12 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         return inputs
 
 
-def _sample(logits_row, temperature, top_p, top_k, generator) -> int:
-    """temperature / top-k / top-p sampling on the fp32 logits (hf:generation/utils.py _sample + logits warpers).
-    Host-side control flow of the slow path; the per-token logits come from the engine."""
-    x = logits_row.float() / float(temperature)
-    if top_k is not None and top_k > 0:
-        kth = torch.topk(x, min(top_k, x.numel())).values[-1]
-        x = torch.where(x < kth, torch.full_like(x, float("-inf")), x)
-    if top_p is not None and top_p < 1.0:
-        sx, si = torch.sort(x, descending=False)
-        cp = torch.softmax(sx, dim=-1).cumsum(-1)
-        remove = cp <= (1 - top_p)
-        remove[-1] = False
-        x = x.masked_fill(torch.zeros_like(remove).scatter(0, si, remove), float("-inf"))
-    p = torch.softmax(x, dim=-1)
-    return int(torch.multinomial(p, 1, generator=generator))
+# Register the model / config with HF's Auto classes (ref:vis_zephyr/model/language_model/vis_zephyr.py:173-174): lets
+# `AutoConfig.from_pretrained` read a `"model_type": "vis_zephyr"` config.json and `AutoModelForCausalLM.from_pretrained(...)`
+# dispatch to VisZephyrForCausalLM.from_pretrained above.
+try:
+    from transformers import AutoConfig, AutoModelForCausalLM
+    AutoConfig.register("vis_zephyr", VisZephyrConfig, exist_ok=True)
+    AutoModelForCausalLM.register(VisZephyrConfig, VisZephyrForCausalLM, exist_ok=True)
+except Exception:                       # pragma: no cover - transformers absent or too old for exist_ok
+    pass

@@ -56,6 +56,8 @@ class VisZephyrMetaForCausalLM:
         """images [T,3,336,336], text_embeddings [T,Lmax,4096] (or [n_samples,Lmax,4096] together with
         `tile_sample`) -> [T,32,4096]   (ref vis_zephyr_arch.py:120-124)."""
         eng = getattr(self, "engine", None)
+        if hasattr(self, "_ensure_ready"):
+            self._ensure_ready()
         if eng is not None and eng.tp_size > 1 and getattr(self, "tile_data_parallel", True):
             return self._encode_images_tile_dp(images, text_embeddings, tile_sample)
         T = int(images.shape[0])
@@ -112,6 +114,8 @@ class VisZephyrMetaForCausalLM:
             # the reference's 4-D branch feeds 2-D text embeddings to the Q-Former and fails inside torch.cat
             # (ref :209-212)
             raise NotImplementedError("`images` must be a list of [N,3,H,W] tensors or a 5-D tensor [B,N,3,H,W]")
+        if hasattr(self, "_ensure_ready"):
+            self._ensure_ready()
         merge_type = getattr(self.config, "mm_patch_merge_type", "flat")
         if merge_type != "flat":
             if merge_type.startswith("spatial"):

@@ -46,14 +46,22 @@ class CLIPVisionTower:
                                num_attention_heads=a.clip_heads, layer_norm_eps=a.clip_eps)
 
     def load_model(self):
-        """The reference loads CLIP weights + CLIPImageProcessor here.  Weights live in the engine (loaded
-        by the model); the image processor is host-side preprocessing and is created on demand."""
+        """ref vision_encoder.py:44-51 loads the CLIP weights + CLIPImageProcessor here (`delay_load`).  Same contract: if the
+        engine has not been given the tower's weights yet (a model built by `from_pretrained`, whose directory holds the
+        language model only), they are streamed in from `vision_tower_path` - a directory or a hub id resolved through the
+        LOCAL HF cache; the image processor is host-side preprocessing and is created on demand."""
+        eng = self._owner.engine
+        if "clip.0.qkv.w" not in eng.w:
+            from vz_hip import weights as W
+            for name, t in W.iter_clip(W.resolve_hub_path(self.vision_tower_path, "mm_vision_tower")):
+                eng.add_weight(name, t)
         if self.image_processor is None:
             self.image_processor = _make_image_processor(self.vision_tower_path, self._owner.arch.clip_image)
         self.is_loaded = True
 
     @torch.no_grad()
     def forward(self, images):
+        self._owner._ensure_ready()
         eng = self._owner.engine
         if isinstance(images, list):
             return [eng.clip_fused_features(im if im.ndim == 4 else im.unsqueeze(0)).to(im.dtype) for im in images]
@@ -91,6 +99,11 @@ def _make_image_processor(path, size):
     except Exception:       # transformers absent: preprocessing is the caller's business
         return None
     import os
+    try:
+        from vz_hip import weights as W
+        path = W.resolve_hub_path(path, "mm_vision_tower")
+    except FileNotFoundError:
+        pass
     if os.path.isdir(path) and os.path.exists(os.path.join(path, "preprocessor_config.json")):
         return CLIPImageProcessor.from_pretrained(path)
     return CLIPImageProcessor(size={"shortest_edge": size}, crop_size={"height": size, "width": size}, resample=3,

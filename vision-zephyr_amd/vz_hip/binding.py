@@ -16,6 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libviszephyr_hip.so")
 
 VZ_OK, VZ_ERR_ARG, VZ_ERR_HIP, VZ_ERR_STATE, VZ_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+VZ_ASYNC_FUSED, VZ_ASYNC_STREAMK = 1, 2
+ABI_VERSION = 5
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
 K_GEMM, K_GEMV, K_ATTN, K_ATTN_DEC, K_NORM, K_OTHER = range(6)
 
@@ -78,6 +80,13 @@ SYMBOLS = {
     "vz_prof_enable": (_I, [_P, _I, _I]),
     "vz_prof_read": (_I, [_P, C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "vz_prof_gemm_stamps": (_I, [C.POINTER(C.c_longlong), _I, C.POINTER(_I)]),
+    "vz_op_async_error": (_I, [_P, C.POINTER(_I)]),
+    "vz_test_corrupt_streamk": (_I, [_P, _I, _I, _I]),
+    "vz_engine_unset_weight": (_I, [_P, C.c_char_p]),
+    "vz_llm_decode_sampling": (_I, [_P, _I, _F, _I, _F, C.c_ulonglong, _I]),
+    "vz_llm_decode_ring": (_I, [_P, _P, _I]),
+    "vz_op_vip_point": (_I, [_P, _I, _I, _I, _I, _I, _I, C.c_uint, _P]),
+    "vz_op_sample": (_I, [_P, _I, _I, _F, _I, _F, C.c_ulonglong, _I, _P, _P]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -233,6 +242,24 @@ def argmax(logits):
     ids = torch.empty(logits.shape[0], dtype=torch.int32, device=logits.device)
     check(lib().vz_op_argmax(ptr(logits), logits.shape[0], logits.shape[1], ptr(ids), stream_ptr(logits.device)))
     return ids
+
+
+def sample(logits, temperature: float, top_k: int = 0, top_p: float = 1.0, seed: int = 0, counter: int = 0):
+    """one draw per row of fp32 logits [rows, V] on the device (sampling.hip): int32 [rows]."""
+    _need_cuda(logits)
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.is_contiguous()
+    ids = torch.empty(logits.shape[0], dtype=torch.int32, device=logits.device)
+    check(lib().vz_op_sample(ptr(logits), logits.shape[0], logits.shape[1], float(temperature), int(top_k or 0),
+                             float(1.0 if top_p is None else top_p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter), ptr(ids),
+                             stream_ptr(logits.device)))
+    return ids
+
+
+def op_async_error(device=None) -> int:
+    """async error word of op-level launches on the current stream (VZ_ASYNC_*; 0 = none); blocking, clears it."""
+    err = C.c_int(0)
+    check(lib().vz_op_async_error(stream_ptr(device), C.byref(err)))
+    return err.value
 
 
 def rope_kv(qkv, cos, sin, pos, slot, kcache, vcache, B_, S, Hq, Hkv, D):

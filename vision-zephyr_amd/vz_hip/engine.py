@@ -84,7 +84,24 @@ class Engine:
     # --------------------------------------------------------------------------------------------
     # weights
     # --------------------------------------------------------------------------------------------
+    @staticmethod
+    def _fp8_names(name: str):
+        return (name + "8", name + "s") if name.endswith("lm_head") else (name + "8", name[:-1] + "ws")
+
+    def _drop_fp8_copy(self, name: str):
+        """the e4m3 copy + row scales of a bf16 decode weight are derived data: whoever rewrites (or replaces) the bf16 tensor
+        invalidates them, so that finalize() re-quantises (a second load_weights / LoRA re-merge / resize_vocab on a
+        weight_fp8 engine must not leave decode streaming the OLD e4m3 rows)."""
+        if not (self.weight_fp8 and self._FP8_NAMES.match(name)):
+            return
+        for n in self._fp8_names(name):
+            if n in self.w:
+                del self.w[n]
+                self._registered.discard(n)
+                B.check(self.lib.vz_engine_unset_weight(self.h, n.encode()))
+
     def _dest(self, name: str, shape, dtype) -> torch.Tensor:
+        self._drop_fp8_copy(name)
         t = self.w.get(name)
         if t is None:
             t = torch.zeros(*shape, dtype=dtype, device=self.device)
@@ -279,6 +296,7 @@ class Engine:
         self.cfg = dataclasses.replace(self.cfg, vocab=n)
         self.vp = n
         for name, t in tables.items():
+            self._drop_fp8_copy(name)          # old-size e4m3 table / scales of lm_head
             self.w[name] = t
             self._registered.discard(name)
         self.finalize()
@@ -309,7 +327,7 @@ class Engine:
         tensor is replaced by the exactly-equal dequantised values, so prefill (bf16 MFMA) and decode (fp8 stream) agree."""
         from . import quant
         for name in [n for n in self.w if self._FP8_NAMES.match(n)]:
-            n8, ns = (name + "8", name + "s") if name.endswith("lm_head") else (name + "8", name[:-1] + "ws")
+            n8, ns = self._fp8_names(name)
             if n8 in self.w:
                 continue
             w = self.w[name]
@@ -439,12 +457,27 @@ class Engine:
         B.check(self.lib.vz_llm_decode_steps(self.h, n, B.ptr(out), B.ptr(lg), self._s()))
         return (out, lg) if return_logits else out
 
+    def set_sampling(self, on: bool, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, seed: int = 0, first_counter: int = 1):
+        """tail of every decode step: greedy argmax (off) or the device-side sampler (sampling.hip); applies from the next decode_begin."""
+        B.check(self.lib.vz_llm_decode_sampling(self.h, int(on), float(temperature), int(top_k or 0), float(1.0 if top_p is None else top_p),
+                                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_counter)))
+
+    def set_ring(self, ring: Optional[torch.Tensor]):
+        """host-visible (pinned) int32 ring the step tails write their tokens to (slot = draw counter mod len); None = off."""
+        if ring is not None:
+            assert ring.dtype == torch.int32 and ring.is_pinned() and ring.dim() == 1 and ring.numel() >= 2
+        self._ring_keep = ring
+        B.check(self.lib.vz_llm_decode_ring(self.h, B.ptr(ring), 0 if ring is None else ring.numel()))
+
     def check_async(self):
-        """raise if a bounded device-side wait of the fused decode launch expired since the last check (outputs invalid)."""
+        """raise if a bounded device-side wait expired since the last check (outputs invalid): the hand-off of the one-launch
+        attention half of a batch-1 decode layer, or the stream-K fix-up of the 256^2 GEMM (its tile is NaN, never a stale sum)."""
         err = C.c_int(0)
         B.check(self.lib.vz_engine_async_error(self.h, C.byref(err)))
         if err.value:
-            raise RuntimeError("vz_hip: a device-side hand-off wait expired during decode (outputs invalid); set vz_tune_set(12, 0)")
+            what = {B.VZ_ASYNC_FUSED: "hand-off of the fused decode launch (vz_tune_set(12, 0) turns it off)",
+                    B.VZ_ASYNC_STREAMK: "stream-K fix-up of the 256^2 GEMM (another launch shared its tickets?)"}.get(err.value, f"code {err.value}")
+            raise RuntimeError(f"vz_hip: a bounded device-side wait expired ({what}); outputs since the last check are invalid")
 
     def decode_mode(self):
         """(graph replayed?, RCCL collectives inside the graph?) of the last decode_steps call."""

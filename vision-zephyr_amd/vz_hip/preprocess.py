@@ -135,3 +135,26 @@ class AnyresPreprocessor:
         B.check(B.lib().vz_op_anyres_tiles(B.ptr(glob), B.ptr(resized), nh, nw, px, py, gw, gh, side, B.ptr(self.lut), B.ptr(out),
                                            B.stream_ptr(self.device)))
         return out
+
+
+def vip_point_box(cx: float, cy: float, img_w: int, img_h: int, image_size_anchor: int = 336, aspect_ratio: float = 1.0, radius=None):
+    """the ellipse box the reference's `draw_point` hands to Pillow ('constant' style of vcr_qa / vcr_qar:
+    ref:vis_zephyr/model/vip_processor/conversation_generator.py:143-146, shape_draw.py:130-134)."""
+    if radius is None:
+        radius = max(int(8 * max(img_w, img_h) / image_size_anchor), 1)
+    xr, yr = radius * aspect_ratio, radius / aspect_ratio
+    return (cx - xr, cy - yr, cx + xr, cy + yr)
+
+
+def vip_point_overlay(image: torch.Tensor, boxes, colors) -> torch.Tensor:
+    """The pixel work of `image_blending(shape="point")` on the device: `image` uint8 [H, W, 3] (device tensor, modified in
+    place and returned); one ellipse box (x0, y0, x1, y1 floats, as `draw_point` computes it) and one (r, g, b, a) per
+    instance, composited in order.  The centre of each point is host-side geometry (the reference samples it with scipy's
+    multivariate_normal around the instance box, shape_draw.py:106-128) and stays the caller's."""
+    assert image.dtype == torch.uint8 and image.dim() == 3 and image.shape[2] == 3 and image.is_cuda and image.is_contiguous()
+    h, w = int(image.shape[0]), int(image.shape[1])
+    for box, (r, g, b, a) in zip(boxes, colors):
+        x0, y0, x1, y1 = (int(v) for v in box)           # Pillow's _draw_ellipse: (int) of each double
+        rgba = (int(r) & 255) | ((int(g) & 255) << 8) | ((int(b) & 255) << 16) | ((int(a) & 255) << 24)
+        B.check(B.lib().vz_op_vip_point(B.ptr(image), h, w, x0, y0, x1, y1, rgba, B.stream_ptr(image.device)))
+    return image

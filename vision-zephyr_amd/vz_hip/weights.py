@@ -22,6 +22,33 @@ import torch
 VT_PREFIX = "model.vision_tower.vision_tower."
 
 
+def resolve_hub_path(name_or_path: Optional[str], what: str = "model") -> str:
+    """A local directory is returned as is.  A hub id (`HuggingFaceH4/zephyr-7b-beta`, `openai/clip-vit-large-patch14-336` -
+    ref:script/run_cli.sh:2, ref:checkpoints/vis-zephyr-7b-v1-pretrain/config.json:23) is looked up in the local HF cache
+    ONLY (`local_files_only=True`: there is no network on the box), first through huggingface_hub, then by walking
+    `$HF_HUB_CACHE | $HF_HOME/hub | ~/.cache/huggingface/hub` / models--org--name / snapshots / <newest>."""
+    if name_or_path is None:
+        raise FileNotFoundError(f"{what}: no path given")
+    p = os.path.expanduser(str(name_or_path))
+    if os.path.isdir(p):
+        return p
+    try:
+        from huggingface_hub import snapshot_download
+        return snapshot_download(repo_id=str(name_or_path), local_files_only=True)
+    except Exception:
+        pass
+    roots = [os.environ.get("HF_HUB_CACHE"), os.environ.get("HUGGINGFACE_HUB_CACHE"),
+             os.path.join(os.environ["HF_HOME"], "hub") if os.environ.get("HF_HOME") else None,
+             os.path.join(os.path.expanduser("~"), ".cache", "huggingface", "hub")]
+    folder = "models--" + str(name_or_path).strip("/").replace("/", "--")
+    for root in filter(None, roots):
+        snaps = sorted(glob.glob(os.path.join(root, folder, "snapshots", "*")), key=os.path.getmtime)
+        if snaps:
+            return snaps[-1]
+    raise FileNotFoundError(f"{what} = {name_or_path!r} is neither a local directory nor a snapshot in the local HuggingFace cache "
+                            "(no network access: place the files in a directory, or populate the cache, and pass that)")
+
+
 def _iter_file(path: str) -> Iterator[Tuple[str, torch.Tensor]]:
     if path.endswith(".safetensors"):
         from safetensors import safe_open
@@ -62,6 +89,14 @@ def iter_clip(clip_dir: str) -> Iterator[Tuple[str, torch.Tensor]]:
 
 def iter_projector(path: str) -> Iterator[Tuple[str, torch.Tensor]]:
     for k, v in _iter_file(path):
+        k = k[len("base_model."):] if k.startswith("base_model.") else k
+        k = k[len("model."):] if k.startswith("model.model.") else k
+        yield k, v
+
+
+def normalize_keys(named) -> Iterator[Tuple[str, torch.Tensor]]:
+    """keys as torch.save'd by the trainer (`base_model.` / doubled `model.model.` prefixes) -> the reference's state-dict keys."""
+    for k, v in named:
         k = k[len("base_model."):] if k.startswith("base_model.") else k
         k = k[len("model."):] if k.startswith("model.model.") else k
         yield k, v
