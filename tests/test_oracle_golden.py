@@ -79,3 +79,31 @@ def test_bf16_oracle_stays_in_band_of_fp32(env):
     l16, _ = O.llm_forward(cfg, sd, O.embed_tokens(sd, ids, O.BF16), P=O.BF16)
     rel = float((l16 - l32).norm() / l32.norm())
     assert rel < 2e-2, rel
+
+
+def test_depth32_fixture_is_complete_and_consistent():
+    """tests/golden/pin_l32.npz (oracle/pin_against_reference.py --llm-layers 32 --deep): the 32-layer fixtures the GPU tests
+    in test_depth32_gpu.py compare against.  Re-running the 32-layer oracle needs 37 GB and minutes, so here only what can be
+    checked from the data itself: every key is present, the report's worst stage error is below the pin's bound, and the three
+    precisions order as they must (weight rounding < bf16 band + weight rounding)."""
+    import json
+    import os
+
+    import numpy as np
+    from util import GOLDEN, load_golden
+    g = load_golden(32)
+    meta = json.load(open(os.path.join(GOLDEN, "pin_l32.json")))
+    assert meta["llm_layers"] == 32 and max(v for k, v in meta["report"].items() if "rounding" not in k and "divergence" not in k) <= 5e-5
+    for k in ("A.logits.sub", "A.logits.last", "A16.logits.last", "A.generate.ids", "A16.generate.ids", "E.generate.ids", "E16.generate.ids",
+              "E.step_logits.s64", "E16.step_logits.s64", "E16.logits.last", "E16.step_top2.vals", "E.bf16_oracle.step_logits.s64",
+              "E.w16_on_fp32_ids.step_logits.s64", "B.loss", "C.generate.ids"):
+        assert k in g, k
+    assert g["E.generate.ids"].shape == g["E16.generate.ids"].shape == (1, 128) and g["E16.step_logits.s64"].shape == (128, 500)
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64)))  # noqa: E731
+    e_w = rel(g["E.w16_on_fp32_ids.step_logits.s64"], g["E.step_logits.s64"])
+    e_a = rel(g["E.bf16_oracle.step_logits.s64"], g["E.w16_on_fp32_ids.step_logits.s64"])
+    e_t = rel(g["E.bf16_oracle.step_logits.s64"], g["E.step_logits.s64"])
+    assert 1e-3 < e_w < 0.1 and 1e-3 < e_a < 0.1 and e_t < e_w + e_a + 1e-3
+    # the reference's own fp32 and W16 runs agree on the first token and on argmax = id at every step of their own runs
+    assert int(np.argmax(g["E16.logits.last"])) == int(g["E16.generate.ids"][0, 0])
+    assert (g["E16.step_top2.ids"][:, 0] == g["E16.generate.ids"][0]).all()
