@@ -11,8 +11,11 @@ One "step" = one full `VisZephyrForCausalLM.generate` on that request, inputs re
   image->first-token  = tiles+ids -> CLIP -> fusion -> Q-Former -> splice -> 32-layer prefill -> argmax
   decode              = 127 further tokens against the KV cache.
 `value` = decode tokens/s (whole job); `image_to_first_token_ms` rides in the same JSON line.
-N > 1: one process per GPU, each serving its own request (the reference's own multi-GPU inference
-scheme, ref:script/eval/eval_qa.sh:21-47) - replicas, no data-path collective, weak scaling.
+N > 1: one process per GPU.  `value` = ONE request over the partition the north star names: Zephyr tensor-parallel over the N
+GPUs (RCCL all-reduce / all-gather over xGMI inside the per-token graph) + the image tiles dealt over the same group
+(tile data parallelism, one all-gather of visual tokens) - "scaling": "strong".  Beside it, as `replicas`: one request per GPU,
+no data-path collective (the reference's own multi-GPU inference scheme, ref:script/eval/eval_qa.sh:21-47).  The TP engine is
+measured by child processes with a time limit; if RCCL fails there the line falls back to the replica numbers and says so.
 
 Extra objects: `roofline` (the dominant kernel by time: the decode weight-streaming GEMV, HBM-bound;
 HIP events on the launch stream in an instrumented replay of decode steps right after the timed
@@ -63,11 +66,73 @@ def algorithmic_work(cfg, S, n_tiles):
 def pmc_traffic():
     """HBM read bytes per GEMV launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in its own run, x1024 x2
     per the gfx950 correction); PMC counters cannot be read from inside this process."""
-    try:
-        with open(os.path.join(REPO, "profiles", "r01_pmc_gemv_fetch.json")) as f:
-            return int(json.load(f)["hbm_read_bytes_per_launch"])
-    except Exception:
-        return None
+    for name in ("r02_pmc_gemv_fetch.json", "r01_pmc_gemv_fetch.json"):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                return int(json.load(f)["hbm_read_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
+
+
+def parity_check(model, ids, tiles, n_layers):
+    """the request of this bench against the REFERENCE's own output for it (tests/golden/pin_l32_c2.npz: BASELINE configs[2] through
+    the imported reference on bf16-rounded weights, fp32 arithmetic - oracle/pin_against_reference.py --configs2): the first
+    token must be the reference's, the prefill's last-row logits must sit in the bf16 band, and the greedy ids are compared
+    until the first near-tie.  Runs outside the timed region."""
+    import numpy as np
+    path = os.path.join(REPO, "tests", "golden", f"pin_l{n_layers}_c2.npz")
+    if not os.path.exists(path):
+        return {"checked": False, "why": f"no fixture for {n_layers} layers"}
+    g = np.load(path)
+    eng = model.engine
+    emb = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles])[4]
+    _, last = eng.prefill(emb, [emb.shape[1]])
+    lo = last[0].float().cpu().numpy().astype(np.float64)
+    ref = g["F16.logits.last"].astype(np.float64)
+    rel = float(np.linalg.norm(lo - ref) / np.linalg.norm(ref))
+    n = int(g["F16.generate.ids"].shape[1])
+    got = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n, eos_token_id=None, pad_token_id=2)[0].tolist()
+    want = g["F16.generate.ids"][0].tolist()
+    first_div = next((i for i in range(n) if got[i] != want[i]), -1)
+    ok = int(np.argmax(lo)) == want[0] == got[0] and rel <= 0.08
+    if not ok:
+        raise AssertionError(f"bench request deviates from the reference: first id {got[0]} vs {want[0]}, last-row logits rel-L2 {rel:.3e}")
+    return {"checked": True, "reference": "W16 (reference code, bf16-rounded weights, fp32 CPU arithmetic)", "first_id": got[0],
+            "last_row_logits_rel_l2": round(rel, 5), "greedy_ids_equal_until": first_div if first_div >= 0 else n, "of": n}
+
+
+class _Streamer:
+    def __init__(self):
+        self.n = 0
+
+    def put(self, v):
+        self.n += 1
+
+    def end(self):
+        pass
+
+
+def streamer_leg(model, ids, tiles, n_new, steps):
+    """the path script/run_cli.sh takes (ref:vis_zephyr/serve/cli.py:155-182): TextStreamer-style callback + a stopping criterion per
+    token + do_sample at temperature 0.2 (HF's default top_k 50) - per-token graph replay with the device-side sampler, tokens
+    read from the host-visible ring, one step kept in flight."""
+    def one():
+        tm = {}
+        t0 = time.perf_counter()
+        out = model.generate(input_ids=ids, images=[tiles], do_sample=True, temperature=0.2, max_new_tokens=n_new, eos_token_id=None,
+                             pad_token_id=2, seed=1234, streamer=_Streamer(), stopping_criteria=[lambda i, s, **k: False], timing=tm)
+        torch.cuda.synchronize()
+        assert out.shape == (1, n_new)
+        return tm["t_first_token"] - t0, time.perf_counter() - tm["t_first_token"]
+    one()
+    r = [one() for _ in range(steps)]
+    return {"value": round((n_new - 1) * steps / sum(b for _, b in r), 2), "unit": "tokens/s",
+            "image_to_first_token_ms": round(sum(a for a, _ in r) / steps * 1e3, 2),
+            "what": "generate(streamer, stopping_criteria, do_sample=True, temperature=0.2): device-side sampling inside the per-token "
+                    "hipGraph, 4-byte token read-back through a pinned ring, callbacks of token t under step t+1"}
+
+
 
 
 def cpu_baseline(cfg_full, S, n_tiles, n_new):
@@ -165,6 +230,21 @@ def fp8_leg_only(args):
     print(json.dumps(fp8_leg), flush=True)
 
 
+def _dry_model(world):
+    """VZ_BENCH_DRY=1 (tests/test_bench_flow_cpu.py): the multi-rank CONTROL FLOW of this script - rendezvous, barriers, the timed
+    region, max over ranks, the tensor-parallel child processes on their own port, the JSON line - without a GPU call."""
+    class M:
+        arch = None
+
+        def generate(self, timing=None, **kw):
+            time.sleep(0.01)
+            if timing is not None:
+                timing["t_first_token"] = time.perf_counter()
+            time.sleep(0.02)
+            return torch.zeros(1, kw.get("max_new_tokens", 1), dtype=torch.long)
+    return M()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,10 +263,11 @@ def main():
     tune = os.environ.get("VZ_TUNE", "")   # experiments only: "knob=value,..." for vz_tune_set; reported in config when set
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    dry = os.environ.get("VZ_BENCH_DRY", "0") == "1"
     dist = None
     # rehearsal on a one-GPU box: VZ_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and uses gloo for the control-plane
     # collectives (barrier, max of the timings) - the multi-rank control flow runs, the GPUs are not what is measured
-    single_dev = os.environ.get("VZ_BENCH_SINGLE_DEVICE", "0") == "1"
+    single_dev = os.environ.get("VZ_BENCH_SINGLE_DEVICE", "0") == "1" or dry
     if single_dev:
         local_rank = 0
     if world > 1:
@@ -197,35 +278,40 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     device = f"cuda:{local_rank}"
-    torch.cuda.set_device(device)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    if not dry:
+        torch.cuda.set_device(device)
 
-    from vz_hip import binding as B, synth
-    for kv in filter(None, tune.split(",")):
-        k, v = kv.split("=")
-        B.check(B.lib().vz_tune_set(int(k), int(v)))
     n_tiles, n_ids, n_new = 5, 1889, args.new_tokens
     S = (n_ids - 1) + 32 * n_tiles
-    # N > 1: replicas by default (one request per GPU, weak scaling).  VZ_BENCH_PARALLELISM=tp runs ONE request over a
-    # tensor-parallel engine instead (Zephyr sharded over the N GPUs, RCCL all-reduce / all-gather; strong scaling).
+    # N > 1: this process measures REPLICAS (one request per GPU); VZ_BENCH_PARALLELISM=tp (set for the child processes below) runs
+    # ONE request over the tensor-parallel + tile-data-parallel engine instead - the child's numbers become `value`.
     tp_mode = world > 1 and os.environ.get("VZ_BENCH_PARALLELISM", "replicas") == "tp"
-    model = build_model(args.layers, device, max_ctx=S + n_new + 16, tp_size=world if tp_mode else 1,
-                        tp_rank=rank if tp_mode else 0)
-    eng, cfg = model.engine, model.arch
-    tiles = synth.synth_tiles(n_tiles, seed=1).to(device, torch.bfloat16)
-    ids = synth.synth_ids(n_ids, cfg.vocab, image_pos=5, seed=2).unsqueeze(0).to(device)
+    if dry:
+        model, eng, cfg, tiles, ids, B = _dry_model(world), None, None, None, None, None
+    else:
+        from vz_hip import binding as B, synth
+        for kv in filter(None, tune.split(",")):
+            k, v = kv.split("=")
+            B.check(B.lib().vz_tune_set(int(k), int(v)))
+        model = build_model(args.layers, device, max_ctx=S + n_new + 16, tp_size=world if tp_mode else 1,
+                            tp_rank=rank if tp_mode else 0)
+        eng, cfg = model.engine, model.arch
+        tiles = synth.synth_tiles(n_tiles, seed=1).to(device, torch.bfloat16)
+        ids = synth.synth_ids(n_ids, cfg.vocab, image_pos=5, seed=2).unsqueeze(0).to(device)
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def step():
         tm = {}
         t0 = time.perf_counter()
-        out = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n_new, eos_token_id=None,
+        out = model.generate(input_ids=ids, images=None if dry else [tiles], do_sample=False, max_new_tokens=n_new, eos_token_id=None,
                              pad_token_id=2, use_cache=True, timing=tm)
-        torch.cuda.synchronize()
+        sync()
         t2 = time.perf_counter()
         assert out.shape == (1, n_new)
         return tm["t_first_token"] - t0, t2 - tm["t_first_token"]
@@ -246,9 +332,31 @@ def main():
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     elapsed, ttft_sum, dec_sum = stats.tolist()
 
+    # ---- tensor-parallel mode: per-collective time from HIP events (every rank runs the instrumented replay: the collectives need
+    # all of them), so that a multi-GPU run yields xGMI numbers ----
+    xgmi = None
+    if tp_mode and not dry:
+        emb = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles])[4]
+        eng.prof_enable(True, B.K_COMM)
+        _, last = eng.prefill(emb, [S])
+        torch.cuda.synchronize()
+        n_p, ms_p = eng.prof_read()
+        eng.decode_begin(last.argmax(-1).to(torch.int32), [S], [S])
+        eng.prof_enable(True, B.K_COMM)
+        eng.decode_steps(8)
+        torch.cuda.synchronize()
+        n_d, ms_d = eng.prof_read()
+        eng.prof_enable(False)
+        pre_bytes = S * cfg.hidden * 2
+        xgmi = {"prefill_allreduce": {"launches": n_p, "avg_us": round(ms_p / max(1, n_p) * 1e3, 2), "bytes": pre_bytes,
+                                      "algbw_GBps": round(pre_bytes / max(1e-9, ms_p / max(1, n_p) * 1e-3) / 1e9, 1)},
+                "decode_collectives": {"launches": n_d, "avg_us": round(ms_d / max(1, n_d) * 1e3, 2), "bytes": cfg.hidden * 2,
+                                       "per_token_ms": round(ms_d / 8, 4)},
+                "method": "HIP events around every RCCL call of one prefill and 8 eager decode steps after the timed region (rank 0)"}
+
     # ---- roofline legs: instrumented replays of the same work, HIP events on the launch stream ----
-    roof, roof_prefill = None, None
-    if rank == 0 and not tp_mode:          # (a tensor-parallel engine needs every rank inside each collective)
+    roof, roof_prefill, parity, stream_leg = None, None, None, None
+    if rank == 0 and not tp_mode and not dry:          # (a tensor-parallel engine needs every rank inside each collective)
         w_bytes, pre_flops = algorithmic_work(cfg, S, n_tiles)
         n_gemv_per_token = 4 * cfg.n_layers + 1
         emb = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles])[4]
@@ -278,21 +386,27 @@ def main():
                         "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4),
                         "traffic": None, "launches": n_l, "total_ms": round(ms, 3),
                         "algorithmic_flops": pre_flops}
-        # the whole image->first-token phase against the MFMA peak: SURVEY section 8(d) algorithmic work of this request -
-        # CLIP 381.9 GFLOP/tile, Q-Former 1186.7 GFLOP/tile at L = 1888, Zephyr prefill 30.224 TFLOP at S = 2048 minus the
-        # all-position lm_head generate() does not run (0.537 TFLOP) - over the measured latency (attention, norms, splice included)
+        # the whole image->first-token phase against the MFMA peak: the work the engine EXECUTES for this request - CLIP 381.9
+        # GFLOP/tile, Q-Former 1186.7 GFLOP/tile at L = 1888 minus the block-0 rows the reference computes and discards (the
+        # engine runs block 0's self-attention once per sample on the 32 query rows: -705 GFLOP/tile),
+        # Zephyr prefill 30.224 TFLOP at S = 2048 minus the all-position lm_head generate() does not run (0.537 TFLOP) - over
+        # the measured latency (attention, norms, splice included).  `survey_flops` = SURVEY section 8(d)'s figure for the same request.
         if cfg.n_layers == 32 and S == 2048 and n_tiles == 5:
-            ft_flops = n_tiles * (381.9e9 + 1186.7e9) + 30.224e12 - 0.537e12
+            survey_flops = n_tiles * (381.9e9 + 1186.7e9) + 30.224e12 - 0.537e12
+            ft_flops = survey_flops - n_tiles * 705e9
             ft_tf = ft_flops / (ttft_sum / args.steps) / 1e12
             roof_prefill["image_to_first_token"] = {"achieved": round(ft_tf, 1), "unit": "TFLOP/s", "frac": round(ft_tf / MFMA_BF16_PEAK_TF, 4),
-                                                    "algorithmic_flops": ft_flops}
+                                                    "executed_flops": ft_flops, "survey_flops": survey_flops}
+        parity = parity_check(model, ids, tiles, cfg.n_layers)
+        if world == 1:
+            stream_leg = streamer_leg(model, ids, tiles, n_new, args.steps)
 
     # ---- extra leg (never `value`): the same request on the W8A16 engine of SURVEY config 5 - e4m3 weights with per-row
     # power-of-two scales streamed by the decode GEMV, bf16 activations, bf16 MFMA prefill on the dequantised weights.
     # Runs in a CHILD process with a time limit (as the tensor-parallel leg does): whatever happens there - an exception, a
     # stall while the second engine is built - the bf16 line of this process is printed. ----
     fp8_leg = None
-    if world == 1 and not args.no_fp8_leg:
+    if world == 1 and not args.no_fp8_leg and not dry:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--fp8-leg-only", "--steps", str(args.steps), "--layers", str(args.layers),
                "--new-tokens", str(args.new_tokens)]
@@ -306,9 +420,10 @@ def main():
         except subprocess.TimeoutExpired:
             fp8_leg = {"value": None, "error": "W8A16 child timed out after 240 s"}
 
-    # ---- N > 1: a guarded tensor-parallel leg beside the replica measurement.  Every rank starts a CHILD process that
-    # runs this script in tp mode (its own rendezvous port), so a failure or hang inside the collectives cannot take the
-    # replica numbers down with it; rank 0 attaches the child's result (or the reason it is missing). ----
+    # ---- N > 1: the north-star partition - ONE request over the tensor-parallel + tile-data-parallel engine - measured by CHILD
+    # processes (one per rank, this script in tp mode on its own rendezvous port, the same K steps / W warmup, the same barrier +
+    # max-over-ranks timing), so a failure or hang inside the collectives cannot withhold the line; rank 0 takes the child's
+    # numbers as `value` (or falls back to the replica numbers and says why). ----
     tp_leg = None
     if world > 1 and not tp_mode and os.environ.get("VZ_BENCH_TP_LEG", "1") != "0":
         import subprocess
@@ -321,56 +436,74 @@ def main():
         # group lives on its own port, so its rank 0 must host the store itself - otherwise every child waits for a server forever
         for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
             env.pop(k)
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(min(args.steps, 2)), "--warmup", "1",
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(max(1, args.warmup)),
                "--layers", str(args.layers), "--new-tokens", str(args.new_tokens), "--no-cpu-baseline", "--no-fp8-leg"]
+        limit = int(os.environ.get("VZ_BENCH_TP_TIMEOUT", "300"))
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
             if rank == 0:
                 lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 if r.returncode == 0 and lines:
-                    c = json.loads(lines[-1])
-                    tp_leg = {k: c[k] for k in ("value", "unit", "image_to_first_token_ms", "ms_per_step", "scaling")}
-                    tp_leg["parallelism"] = c["config"]["parallelism"]
+                    tp_leg = json.loads(lines[-1])
                 else:
                     tp_leg = {"value": None, "error": f"child rc={r.returncode}: {(r.stderr or '')[-400:]}"}
         except subprocess.TimeoutExpired:
             if rank == 0:
-                tp_leg = {"value": None, "error": "tensor-parallel child timed out after 200 s"}
+                tp_leg = {"value": None, "error": f"tensor-parallel child timed out after {limit} s"}
         barrier()
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
     cpu = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and not dry:
         try:
             cpu = cpu_baseline(cfg, S, n_tiles, n_new)
         except Exception as ex:   # the GPU numbers stand on their own; say why the CPU leg is missing
             cpu = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                    "sample": f"failed: {type(ex).__name__}: {ex}"}
     n_dec_tokens = (n_new - 1) * args.steps * (1 if tp_mode else world)
+    workload = (f"configs[2]: 5 anyres tiles (4 crops + 1 global) + {n_ids}-id prompt -> S={S}, {n_new} greedy new tokens, "
+                f"{args.layers} decoder layers")
     line = {
         "metric": "decode tokens/sec (image->first-token ms alongside), Zephyr-7B anyres 5-tile",
-        "value": round(n_dec_tokens / dec_sum, 2) if world == 1 else round(n_dec_tokens / dec_sum, 2),
+        "value": round(n_dec_tokens / dec_sum, 2),
         "unit": "tokens/s",
         "image_to_first_token_ms": round(ttft_sum / args.steps * 1e3, 2),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2),
         "higher_is_better": True, "scaling": "strong" if tp_mode else "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic (hash-generated weights seed 0, N(0,1) tiles, uniform ids)",
-        "config": {"workload": f"configs[2]: 5 anyres tiles (4 crops + 1 global) + {n_ids}-id prompt -> S={S}, "
-                               f"{n_new} greedy new tokens, batch 1 per GPU",
-                   "layers": cfg.n_layers, "seq_len": S, "new_tokens": n_new,
-                   "parallelism": "single GPU" if world == 1 else (f"tp{world} (one request, Zephyr tensor-parallel over RCCL)" if tp_mode
-                                                                          else f"dp{world} replicas (one request per GPU, no collective)")},
+        "dtype": "bf16", "data": "dry-run (control flow only)" if dry else "synthetic (hash-generated weights seed 0, N(0,1) tiles, uniform ids)",
+        "config": {"workload": workload,
+                   "parallelism": "single GPU" if world == 1 else
+                                  (f"tp{world} + tile-dp{world}: one request, Zephyr tensor-parallel + tiles dealt over the group, RCCL over xGMI" if tp_mode
+                                   else f"dp{world} replicas (one request per GPU, no collective)")},
         "roofline": roof, "roofline_prefill": roof_prefill, "cpu_baseline": cpu,
     }
     if tune:
         line["config"]["tune"] = tune
-    if tp_leg is not None:
-        line["tensor_parallel"] = tp_leg
+    if xgmi is not None:
+        line["xgmi"] = xgmi
+    if parity is not None:
+        line["parity"] = parity
+    if stream_leg is not None:
+        line["streamer_path"] = stream_leg
     if fp8_leg is not None:
         line["fp8_weights"] = fp8_leg
+    if tp_leg is not None:
+        if tp_leg.get("value") is not None:
+            # the north-star partition is the headline; what this process measured (replicas) rides beside it
+            replicas = {k: line[k] for k in ("value", "unit", "image_to_first_token_ms", "ms_per_step", "scaling")}
+            replicas["parallelism"] = line["config"]["parallelism"]
+            for k in ("value", "image_to_first_token_ms", "ms_per_step", "scaling"):
+                line[k] = tp_leg[k]
+            line["config"]["parallelism"] = tp_leg["config"]["parallelism"]
+            if "xgmi" in tp_leg:
+                line["xgmi"] = tp_leg["xgmi"]
+            line["replicas"] = replicas
+        else:
+            line["tensor_parallel"] = tp_leg
+            line["config"]["parallelism"] += " - the tensor-parallel engine did not produce a number (see tensor_parallel.error)"
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

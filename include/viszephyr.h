@@ -276,6 +276,40 @@ int vz_op_resample_u8(const void* d_src, int h, int w, void* d_tmp, void* d_dst,
 int vz_op_anyres_tiles(const void* d_global, const void* d_resized, int nh, int nw, int paste_x, int paste_y, int grid_w,
                        int grid_h, int side, const void* d_lut, void* d_out, vz_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 3. Stage-1 pretrain step
+ *
+ * ref:vis_zephyr/train/train.py:817-829 freezes everything but `mm_projector`; the loss is HF's causal-LM cross-entropy of
+ * ref:vis_zephyr/model/language_model/vis_zephyr.py:51-98 (shift by one, ignore_index -100, mean over the valid targets);
+ * ref:vis_zephyr/train/vis_zephyr_trainer.py:224-302 + ref:script/pretrain.sh:39-42: AdamW on the projector parameters,
+ * DeepSpeed ZeRO-2 data parallelism.  A trainer belongs to one finalized tp_size 1 engine and owns: W^T copies of the frozen
+ * Zephyr linears, fp32 master / Adam moments / gradient arenas of the 165 projector tensors (engine names "qf.*", engine
+ * layout - vz_hip/train.py maps them to the reference's parameter names), and an arena of saved activations + scratch.
+ *   vz_train_stage1_accumulate  forward (activations kept) + backward of ONE micro-batch; gradients ACCUMULATE.  Stage inputs
+ *       as the inference entry points take them (vz_clip_fused_features / vz_qformer / vz_embed_splice / vz_llm_prefill) plus
+ *       d_vis_rows int32 [T*32] (row of [B*S] each visual token was spliced into, -1 = cut off), d_labels int32 [B,S] (HF
+ *       labels; the shift happens inside) and inv_n = 1 / (valid targets of the whole batch).
+ *   vz_train_loss_sum           sum over the rows of the last micro-batch of (logsumexp - target logit)  (blocking)
+ *   vz_train_allreduce          RCCL all-reduce (sum) of the flat gradient arena, 256 MiB buckets; no-op without vz_train_comm_init
+ *   vz_train_adamw_step         torch.optim.AdamW (no amsgrad) on every projector tensor; rewrites the engine's working copies,
+ *                               clears the gradients
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vz_trainer vz_trainer;
+int vz_train_create(vz_engine* e, vz_trainer** out, vz_stream stream);
+int vz_train_destroy(vz_trainer* t);
+int vz_train_set_master(vz_trainer* t, const char* engine_name, const float* d_values, long n, vz_stream stream);
+int vz_train_param_count(vz_trainer* t);
+int vz_train_param_info(vz_trainer* t, int i, const char** name, long* n, long* offset, int* is_matrix);
+int vz_train_arenas(vz_trainer* t, float** d_grad, float** d_master, float** d_m, float** d_v, long* total_floats);
+int vz_train_stage1_accumulate(vz_trainer* t, const void* d_images, int T, const void* d_text, int n_samples, int Lmax,
+                               const int* h_tile_sample, const int* d_kind, const int* d_idx, const int* d_vis_rows, int B, int S,
+                               const int* h_seqlens, const int* d_pos, const int* d_labels, float inv_n, vz_stream stream);
+int vz_train_loss_sum(vz_trainer* t, double* out, vz_stream stream);
+int vz_train_zero_grad(vz_trainer* t, vz_stream stream);
+int vz_train_comm_init(vz_trainer* t, const char* id128, int rank, int world);
+int vz_train_allreduce(vz_trainer* t, vz_stream stream);
+int vz_train_adamw_step(vz_trainer* t, float lr, float beta1, float beta2, float eps, float weight_decay, vz_stream stream);
+
 /* ViP "point" overlay on the device (ref:vis_zephyr/model/vip_processor/conversation_generator.py:143-153,170-175: the
  * `vcr_qa` / `vcr_qar` visual prompt = `ImageDraw.ellipse(box, fill=rgba, outline=rgba)` on a transparent canvas +
  * `Image.alpha_composite` + convert("RGB")): composites one filled ellipse with the INTEGER box (x0, y0, x1, y1) - the
@@ -297,7 +331,7 @@ int vz_tune_set(int knob, int value);
 
 /* per-kernel-class timing of the engine's launches with HIP events on the launch stream (bench.py's roofline
  * leg).  enable=1 disables graph replay and brackets every launch of class `klass` with events.
- * classes: 0 gemm(mfma) 1 gemv 2 attention 3 attn_decode 4 norm 5 other */
+ * classes: 0 gemm(mfma) 1 gemv 2 attention 3 attn_decode 4 norm 5 other 6 fused attention half 7 RCCL collectives */
 int vz_prof_enable(vz_engine* e, int enable, int klass);
 /* synchronises the events; returns launches counted and their total milliseconds */
 int vz_prof_read(vz_engine* e, long* n_launches, double* total_ms);

@@ -140,6 +140,35 @@ def _case_e(model, cfg, sd, fx, report, check, tag, P, tiles, ids, n_new, t0):
     return m[4], gen, step_ref
 
 
+def configs2_case(model, cfg, sd, args, t0):
+    """bench.py's request (5 tiles seed 1, 1889 ids seed 2 with the image sentinel at 5), W16 reference: last-row logits of the
+    prefill, 16 greedy ids with their step logits (subsampled) and top-2 gaps.  The oracle is checked on the prefill's last row
+    (its full S=2048 forward) - the per-stage checks at this depth are the --deep run's."""
+    n_new = 16
+    _round_matrices_in_place(sd)
+    tiles = synth.synth_tiles(5, seed=1).to(torch.bfloat16).float()
+    ids = synth.synth_ids(1889, cfg.vocab, image_pos=5, seed=2).unsqueeze(0)
+    g = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n_new, use_cache=True, eos_token_id=None,
+                       pad_token_id=2, return_dict_in_generate=True, output_logits=True)
+    step_ref = torch.stack([x[0].float() for x in g.logits], 0)
+    print(f"[pin] configs[2] reference generate done {time.time() - t0:.0f}s ids={g.sequences[0].tolist()}", flush=True)
+    m = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids, None, None, None, None, [tiles])
+    assert tuple(m[4].shape) == (1, 2048, cfg.hidden)
+    lo, _ = O.llm_forward(cfg, sd, m[4], last_only=True)
+    e = rel_err(lo[0, -1], step_ref[0])
+    print(f"[pin] F16.logits.last rel_err {e:.3e}", flush=True)
+    assert e <= 5e-5
+    fx = {"F16.generate.ids": g.sequences.numpy().astype(np.int64), "F16.logits.last": step_ref[0].numpy().astype(np.float32),
+          "F16.step_logits.s64": step_ref[:, ::64].numpy().astype(np.float32)}
+    fx["F16.step_top2.ids"], fx["F16.step_top2.vals"] = _top2(step_ref)
+    np.savez_compressed(os.path.join(args.out, f"pin_l{args.llm_layers}_c2.npz"), **fx)
+    with open(os.path.join(args.out, f"pin_l{args.llm_layers}_c2.json"), "w") as f:
+        json.dump(dict(llm_layers=args.llm_layers, oracle_vs_reference_last_row=e, torch=torch.__version__,
+                       transformers=__import__("transformers").__version__,
+                       note="BASELINE configs[2] through the reference with bf16-rounded matrices and tiles (W16), fp32 arithmetic, CPU"), f, indent=1)
+    print(f"[pin] OK - configs[2] fixtures written ({time.time() - t0:.0f}s)")
+
+
 def deep_cases(model, cfg, sd, fx, report, check, t0):
     n_new = 128
     tiles_a = synth.synth_tiles(3, seed=1)
@@ -203,6 +232,9 @@ def main():
     ap.add_argument("--deep", action="store_true",
                     help="also pin case E (BASELINE configs[1]: 1 tile + 481 ids -> S=512, 128 greedy tokens) and re-run cases "
                          "A and E through the reference with its matrices rounded to bf16 in place (the W16 model)")
+    ap.add_argument("--configs2", action="store_true",
+                    help="ONLY BASELINE configs[2] (5 tiles + 1889 ids -> S=2048, 16 greedy tokens) through the W16 reference "
+                         "(matrices rounded to bf16 in place) -> pin_l<k>_c2.npz: what bench.py checks its own request against")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -215,6 +247,8 @@ def main():
     print(f"[pin] weights loaded {time.time() - t0:.0f}s", flush=True)
     report = {}
     fx = {}
+    if args.configs2:
+        return configs2_case(model, cfg, sd, args, t0)
 
     def check(name, mine, ref, tol=1e-5):
         e = rel_err(mine, ref)

@@ -42,15 +42,17 @@ def stage1_loss(cfg, sd, input_ids, attention_mask, labels, images, P: O.Prec = 
     return F.cross_entropy(logits[:, :-1].float().reshape(-1, V), lab[:, 1:].reshape(-1), ignore_index=O.IGNORE_INDEX)
 
 
-def stage1_grads(cfg, sd, input_ids, attention_mask, labels, images) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-    """(loss, {projector parameter name: dLoss/dparam}) in fp32; every other weight is a constant, as in Stage 1."""
+def stage1_grads(cfg, sd, input_ids, attention_mask, labels, images, P: O.Prec = O.FP32) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    """(loss, {projector parameter name: dLoss/dparam}) in fp32; every other weight is a constant, as in Stage 1.
+    With P = BF16 the forward rounds where the HIP path stores bf16 and - because autograd's backward of a dtype cast casts the
+    gradient too - so does the backward: the bf16 band of the gradients."""
     train = dict(sd)
     leaves = {}
     for k in projector_keys(sd):
         leaves[k] = sd[k].detach().clone().requires_grad_(True)
         train[k] = leaves[k]
     with torch.enable_grad():
-        loss = stage1_loss(cfg, train, input_ids, attention_mask, labels, images)
+        loss = stage1_loss(cfg, train, input_ids, attention_mask, labels, images, P)
         loss.backward()
     return loss.detach(), {k: v.grad for k, v in leaves.items()}
 

@@ -138,7 +138,7 @@ extern "C" int vz_op_argmax(const float* logits, int rows, int cols, int* ids, v
 // ------------------------------------------------------------------------------------------------
 struct Weight { const void* p; int dtype; long n; };
 
-enum { K_GEMM = 0, K_GEMV = 1, K_ATTN = 2, K_ATTN_DEC = 3, K_NORM = 4, K_OTHER = 5, K_FUSED = 6 };
+enum { K_GEMM = 0, K_GEMV = 1, K_ATTN = 2, K_ATTN_DEC = 3, K_NORM = 4, K_OTHER = 5, K_FUSED = 6, K_COMM = 7 };
 
 struct vz_engine {
     vz_config c;
@@ -668,7 +668,7 @@ static inline bool tp_skip(const vz_engine* e) { return e->tp > 1 && g_force_com
 static int tp_allreduce_bf16(vz_engine* e, bf16_t* buf, size_t count, hipStream_t s) {
     if (tp_local(e) || tp_skip(e)) return VZ_OK;
     if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
-    ProfScope ps(e, K_OTHER, s);
+    ProfScope ps(e, K_COMM, s);
     ncclResult_t r = ncclAllReduce(buf, buf, count, ncclBfloat16, ncclSum, e->comm, s);
     if (r != ncclSuccess) { vz_set_error("ncclAllReduce failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
     return VZ_OK;
@@ -711,7 +711,8 @@ static int lm_head_logits(vz_engine* e, const bf16_t* h, int rows, float* out, h
         VZ_CHECK_HIP(hipMemcpyAsync(e->d_gather + (size_t)e->rank * rows * e->Vp, local, (size_t)rows * e->Vp * sizeof(float), hipMemcpyDeviceToDevice, s));
         return vz_launch_repack_logits(e->d_gather, out, rows, e->Vp, c.vocab, e->tp, s);
     }
-    ncclResult_t r = ncclAllGather(local, e->d_gather, (size_t)rows * e->Vp, ncclFloat, e->comm, s);
+    ncclResult_t r;
+    { ProfScope ps(e, K_COMM, s); r = ncclAllGather(local, e->d_gather, (size_t)rows * e->Vp, ncclFloat, e->comm, s); }
     if (r != ncclSuccess) { vz_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
     return vz_launch_repack_logits(e->d_gather, out, rows, e->Vp, c.vocab, e->tp, s);
 }
@@ -746,7 +747,7 @@ extern "C" int vz_tp_all_gather(vz_engine* e, const void* d_send, void* d_recv, 
         return VZ_OK;
     }
     if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
-    ProfScope ps(e, K_OTHER, s);
+    ProfScope ps(e, K_COMM, s);
     ncclResult_t r = ncclAllGather(d_send, d_recv, bytes_per_rank, ncclInt8, e->comm, s);
     if (r != ncclSuccess) { vz_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
     return VZ_OK;
@@ -980,7 +981,8 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
 // and counter 0, so it passes 1).  enable = 0: greedy.
 extern "C" int vz_llm_decode_sampling(vz_engine* e, int enable, float temperature, int top_k, float top_p, unsigned long long seed,
                                       int first_counter) {
-    VZ_CHECK_ARG(e, "decode_sampling: null engine");
+    VZ_CHECK_ARG(e && first_counter >= 0, "decode_sampling: null engine / negative counter");
+    e->samp_ctr0 = first_counter;        // the draw counter also indexes the host-visible token ring of a greedy streamer loop
     if (!enable) { e->samp_on = 0; return VZ_OK; }
     VZ_CHECK_ARG(temperature > 0.f && top_k >= 0 && top_p > 0.f && top_p <= 1.f && first_counter >= 0,
                  "decode_sampling: temperature %g > 0, top_k %d >= 0, 0 < top_p %g <= 1 expected", (double)temperature, top_k, (double)top_p);
@@ -1055,8 +1057,8 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
         for (int bk : buckets) if (bk >= need) { ns = std::min(bk, e->nsplit); break; }
         e->dec_nsplit = g_attn_nsplit > 0 ? g_attn_nsplit : ns;
         for (int b = 0; b < B; ++b) {       // what the device-side state will be after these n steps (the tail saturates, so do we)
-            e->h_len[b] = std::min(e->h_len[b] + n, c.max_ctx);
-            e->h_pos[b] = std::min(e->h_pos[b] + n, e->rope_max - 1);
+            if (e->h_parked[b]) { e->h_len[b] = std::min(e->h_len[b] + n, c.max_ctx); e->h_pos[b] = std::min(e->h_pos[b] + n, e->rope_max - 1); }
+            else { e->h_len[b] += n; e->h_pos[b] += n; }      // a live row that is full is refused by the check above on the next call
         }
     }
     if (!use_graph) {
@@ -1177,3 +1179,5 @@ extern "C" int vz_prof_read(vz_engine* e, long* n_launches, double* total_ms) {
     e->prof_used = 0;
     return VZ_OK;
 }
+
+#include "train_engine.inc"

@@ -32,6 +32,10 @@ struct GemmParams {
     int M, N, K, lda, ldw, ldc, ldr;
     int act, out_fp32, tiles_m, tiles_n;
     int splitk; float* slab;   // splitk > 1: fp32 partial tiles go to slab[split][M][N], epilogue runs in splitk_finalize_kernel
+    // batched launches (blockIdx.y = o * n_inner + i; the training step's attention contractions over (sample, head)): element
+    // offsets o * so + (i / div) * si per operand; n_inner == 0: a single problem
+    int n_inner; int a_div, w_div;
+    long a_so, a_si, w_so, w_si, c_so, c_si;
 };
 
 __device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
@@ -104,6 +108,12 @@ __device__ __forceinline__ void epilogue_fast(const GemmParams& p, f32x4 (&acc)[
 
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.n_inner > 0) {
+        const int o = blockIdx.y / p.n_inner, i = blockIdx.y - o * p.n_inner;
+        p.A += o * p.a_so + (i / p.a_div) * p.a_si;
+        p.W += o * p.w_so + (i / p.w_div) * p.w_si;
+        p.C = p.out_fp32 ? (void*)((float*)p.C + o * p.c_so + i * p.c_si) : (void*)((bf16_t*)p.C + o * p.c_so + i * p.c_si);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves, 64(m) x 64(n) each
 
@@ -375,7 +385,7 @@ int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
         if (splitk > 4) splitk = 4;
         while (splitk > 1 && nk / splitk < 8) --splitk;
     }
-    p.splitk = splitk; p.slab = nullptr;
+    p.splitk = splitk; p.slab = nullptr; p.n_inner = 0; p.a_div = p.w_div = 1; p.a_so = p.a_si = p.w_so = p.w_si = p.c_so = p.c_si = 0;
     if (splitk > 1) {
         const size_t need = (size_t)splitk * a.M * a.N * sizeof(float);
         if (need > g_slab_bytes) {
@@ -393,6 +403,31 @@ int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(splitk_finalize_kernel, dim3((int)blocks), dim3(256), 0, s, p);
         VZ_LAUNCH_CHECK();
     }
+    return VZ_OK;
+}
+
+// n_outer x n_inner independent products C_b = A_b . W_b^T on the 128^2 kernel (no bias / residual / activation, no split-K):
+// operand b = (o, i) starts at base + o * so + (i / div) * si elements - `div` lets the 4 query heads of a KV head share one W
+int vz_launch_gemm_batched(const BatchedGemmArgs& b, hipStream_t s) {
+    LinearArgs a;
+    a.A = b.A; a.lda = b.lda; a.W = b.W; a.ldw = b.ldw; a.C = b.C; a.ldc = b.ldc; a.M = b.M; a.N = b.N; a.K = b.K;
+    a.bias = nullptr; a.residual = nullptr; a.ldr = 0; a.act = VZ_ACT_NONE; a.out_fp32 = b.out_fp32; a.norm_w = nullptr; a.norm_eps = 0.f;
+    int rc = vz_linear_check_common(a);
+    if (rc) return rc;
+    VZ_CHECK_ARG(b.n_outer >= 1 && b.n_inner >= 1 && (long)b.n_outer * b.n_inner <= 65535 && b.a_div >= 1 && b.w_div >= 1, "gemm_batched: bad batch");
+    VZ_CHECK_ARG((b.a_so % 8) == 0 && (b.a_si % 8) == 0 && (b.w_so % 8) == 0 && (b.w_si % 8) == 0 && (b.c_so % 4) == 0 && (b.c_si % 4) == 0,
+                 "gemm_batched: batch strides must keep 16-byte alignment");
+    { int r = vz_init_gemm_kernels(); if (r) return r; }
+    GemmParams p;
+    p.A = a.A; p.W = a.W; p.C = a.C; p.bias = nullptr; p.residual = nullptr;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = 0;
+    p.act = VZ_ACT_NONE; p.out_fp32 = a.out_fp32;
+    p.tiles_m = (a.M + BM - 1) / BM; p.tiles_n = (a.N + BN - 1) / BN;
+    p.splitk = 1; p.slab = nullptr;
+    p.n_inner = b.n_inner; p.a_div = b.a_div; p.w_div = b.w_div;
+    p.a_so = b.a_so; p.a_si = b.a_si; p.w_so = b.w_so; p.w_si = b.w_si; p.c_so = b.c_so; p.c_si = b.c_si;
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(p.tiles_m * p.tiles_n, b.n_outer * b.n_inner), dim3(256), GEMM_LDS, s, p);
+    VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
 

@@ -1,0 +1,523 @@
+// Backward kernels of the Stage-1 pretrain step (ref:vis_zephyr/train/train.py:817-829 trains the
+// Q-Former projector only, through the frozen Zephyr, on HF's causal-LM cross-entropy; ref:script/pretrain.sh:39-42 AdamW).
+// Restated on the CPU in oracle/train_oracle.py (autograd through the pinned forward restatement).
+//
+// Every contraction of the backward runs on the forward's MFMA tile GEMMs (gemm.hip / gemm256.hip compute C = A . W^T with both
+// operands K-contiguous):
+//     input gradient   dX[R,K] = dY[R,N] . W[N,K]        ->  A = dY,   "W" = W^T [K,N]   (frozen Zephyr weights: transposed once at
+//                                                             set-up; projector weights: transposed every step, 3.4 GB)
+//     weight gradient  dW[N,K] = dY^T[N,R] . X[R,K]      ->  A = dY^T, "W" = X^T [K,R]   (rows R are the contraction; fp32 out)
+//     attention        S = Q K^T, dP = dO V^T, dQ = dS K, dK = dS^T Q, dV = P^T dO as BATCHED tile GEMMs over (sample, head) with the
+//                      probabilities materialised (Stage-1 sequences are ~200 tokens: P is 160 MB per layer), 4 query heads of a
+//                      KV head concatenated along the contraction for dK / dV (the GQA sum comes out of the GEMM)
+// so what lives here is the data movement around them (zero-padded batched transposes) and the row-wise / element-wise
+// derivatives: masked softmax forward + backward, RMSNorm / LayerNorm backward (dx, and per-workgroup partial sums of dw / db that a
+// second kernel adds in a fixed order: no float atomics, gradients are reproducible bit for bit), SwiGLU / exact-GELU backward,
+// RoPE backward + re-assembly of the fused-QKV gradient, cross-entropy (loss + dlogits in one pass pair), column sums for the bias
+// gradients, the fused AdamW update.  All HBM-bound: 16-byte accesses where the layout allows, one wave or one workgroup per row.
+#include "vz_common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {     // 256 threads = 4 waves; result in every thread
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// dst[o][i][c][col0 + r] = src[o][i][r][c]   (bf16; 32 x 32 tiles through LDS; the caller zero-fills dst's padding)
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, long src_rs, long src_so, long src_si,
+                                                        bf16_t* __restrict__ dst, long dst_rs, long dst_so, long dst_si, int R, int C,
+                                                        int n_inner, int col0) {
+    __shared__ bf16_t tile[32][33];
+    const int batch = blockIdx.z, o = batch / n_inner, i = batch - o * n_inner;
+    const bf16_t* s = src + o * src_so + i * src_si;
+    bf16_t* d = dst + o * dst_so + i * dst_si;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + k * 8, c = c0 + tx;
+        tile[ty + k * 8][tx] = (r < R && c < C) ? s[(size_t)r * src_rs + c] : (bf16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + k * 8, r = r0 + tx;
+        if (c < C && r < R) d[(size_t)c * dst_rs + col0 + r] = tile[tx][ty + k * 8];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// masked softmax over fp32 score rows: P[row][j] = softmax_j(scale * S[row][j]) over the keys the query may see, 0 elsewhere
+// (incl. the padding columns up to ldp).  One wave per row.  row = ((b * H + h) * Sq + i); query i of batch b sits at position i.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, int lds_, bf16_t* __restrict__ P, int ldp, long rows,
+                                                          int H, int Sq, int Sk, float scale, int causal, int window,
+                                                          const int* __restrict__ kv_len) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(row % Sq), b = (int)(row / ((long)Sq * H));
+    int hi = kv_len ? kv_len[b] : Sk;                 // keys [lo, hi) are visible
+    hi = hi < Sk ? hi : Sk;
+    int lo = 0;
+    if (causal) { hi = hi < i + 1 ? hi : i + 1; if (window > 0 && i + 1 - window > 0) lo = i + 1 - window; }
+    const float* s = S + row * lds_;
+    bf16_t* p = P + row * ldp;
+    float m = -INFINITY;
+    for (int j = lo + lane; j < hi; j += 64) m = fmaxf(m, s[j] * scale);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lo + lane; j < hi; j += 64) l += __expf(s[j] * scale - m);
+    l = wave_sum(l);
+    const float inv = hi > lo ? 1.f / l : 0.f;
+    for (int j = lane; j < ldp; j += 64) p[j] = (j >= lo && j < hi) ? f32_to_bf16(__expf(s[j] * scale - m) * inv) : (bf16_t)0;
+}
+
+// dS = P o (dP - sum_j P dP) * scale   (bf16 out, zero where P is zero)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ P, int ldp, const float* __restrict__ dP, int lddp,
+                                                          bf16_t* __restrict__ dS, int ldds, long rows, int Sk, float scale) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const bf16_t* p = P + row * ldp;
+    const float* dp = dP + row * lddp;
+    bf16_t* ds = dS + row * ldds;
+    // (a masked position has P == 0 exactly; dP there was computed against cache rows nobody wrote - never touch it)
+    float d = 0.f;
+    for (int j = lane; j < Sk; j += 64) { const float pv = bf16_to_f32(p[j]); if (pv != 0.f) d += pv * dp[j]; }
+    d = wave_sum(d);
+    for (int j = lane; j < ldds; j += 64) {
+        const float pv = j < Sk ? bf16_to_f32(p[j]) : 0.f;
+        ds[j] = pv != 0.f ? f32_to_bf16(pv * (dp[j] - d) * scale) : (bf16_t)0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// RMSNorm backward (hf:models/mistral/modeling_mistral.py:182-199; the scale is frozen in Stage 1: dx only):
+//   r = rsqrt(mean(x^2) + eps), xh = x r, g = dy w:  dx = r (g - xh mean(g xh)) [+ dres]
+// One wave per row of `cols` <= 8192.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const bf16_t* __restrict__ dy,
+                                                          const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, long rows, int cols, float eps) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const bf16_t* xr = x + row * cols;
+    const bf16_t* gr = dy + row * cols;
+    float ss = 0.f, gx = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float xv = bf16_to_f32(xr[c]); ss += xv * xv; gx += bf16_to_f32(gr[c]) * w[c] * xv; }
+    ss = wave_sum(ss); gx = wave_sum(gx);
+    const float r = rsqrtf(ss / cols + eps);
+    const float k = gx * r * r / cols;            // mean(g xh) r = sum(g x) r^2 / cols ... applied to xh = x r below
+    for (int c = lane; c < cols; c += 64) {
+        const float xv = bf16_to_f32(xr[c]);
+        float v = r * (bf16_to_f32(gr[c]) * w[c] - xv * k);
+        if (dres) v += bf16_to_f32(dres[row * cols + c]);
+        dx[row * cols + c] = f32_to_bf16(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward with parameter gradients (torch.nn.LayerNorm of the Q-Former, ref:...multimodal_projector/builder.py:14-27,68-70).
+// Workgroup g takes rows g, g + G, ...; thread t owns columns t, t + 256, ... (<= 20 of them: cols <= 5120) and keeps their dw / db
+// partial sums in registers across its rows; written to part[g][2][cols] at the end and added by layernorm_bwd_reduce_kernel in
+// workgroup order.  dx (optional) = rstd (g - mean(g) - xh mean(g xh)) [+ dres], g = dy w.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAX_PER_THREAD = 20;
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const bf16_t* __restrict__ dy,
+                                                            const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, float* __restrict__ part,
+                                                            long rows, int cols, float eps) {
+    __shared__ float red[4];
+    const int t = threadIdx.x, per = (cols + 255) / 256;
+    float dwp[LN_MAX_PER_THREAD], dbp[LN_MAX_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < LN_MAX_PER_THREAD; ++k) { dwp[k] = 0.f; dbp[k] = 0.f; }
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const bf16_t* xr = x + row * cols;
+        const bf16_t* gr = dy + row * cols;
+        float xv[LN_MAX_PER_THREAD], gv[LN_MAX_PER_THREAD];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAX_PER_THREAD; ++k) {
+            const int c = t + k * 256;
+            const bool in = k < per && c < cols;
+            xv[k] = in ? bf16_to_f32(xr[c]) : 0.f;
+            gv[k] = in ? bf16_to_f32(gr[c]) : 0.f;
+            s += xv[k];
+        }
+        const float mean = block_sum_256(s, red) / cols;
+        float vs = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAX_PER_THREAD; ++k) { const int c = t + k * 256; if (k < per && c < cols) { const float d = xv[k] - mean; vs += d * d; } }
+        const float rstd = rsqrtf(block_sum_256(vs, red) / cols + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAX_PER_THREAD; ++k) {
+            const int c = t + k * 256;
+            if (k < per && c < cols) {
+                const float xh = (xv[k] - mean) * rstd, g = gv[k] * w[c];
+                xv[k] = xh;
+                sg += g; sgx += g * xh;
+                dwp[k] += gv[k] * xh; dbp[k] += gv[k];
+            }
+        }
+        if (dx) {                  // (uniform over the workgroup)
+            const float mg = block_sum_256(sg, red) / cols, mgx = block_sum_256(sgx, red) / cols;
+#pragma unroll
+            for (int k = 0; k < LN_MAX_PER_THREAD; ++k) {
+                const int c = t + k * 256;
+                if (k < per && c < cols) {
+                    float v = rstd * (gv[k] * w[c] - mg - xv[k] * mgx);
+                    if (dres) v += bf16_to_f32(dres[row * cols + c]);
+                    dx[row * cols + c] = f32_to_bf16(v);
+                }
+            }
+        }
+    }
+    float* pw = part + (size_t)blockIdx.x * 2 * cols;
+#pragma unroll
+    for (int k = 0; k < LN_MAX_PER_THREAD; ++k) {
+        const int c = t + k * 256;
+        if (k < per && c < cols) { pw[c] = dwp[k]; pw[cols + c] = dbp[k]; }
+    }
+}
+// dw[c] += sum_g part[g][0][c], db[c] += sum_g part[g][1][c]   (fixed order)
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ part, int G, int cols, float* __restrict__ dw,
+                                                                   float* __restrict__ db) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * cols) return;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += part[(size_t)g * 2 * cols + c];
+    if (c < cols) dw[c] += s; else db[c - cols] += s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// element-wise derivatives
+// ---------------------------------------------------------------------------------------------------------------------------
+// exact GELU forward on a saved pre-activation (training keeps h, the inference epilogue fuses it away) and its backward
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = f32_to_bf16(act_gelu_erf(bf16_to_f32(h[i])));
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dh, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float x = bf16_to_f32(h[i]);
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+        dh[i] = f32_to_bf16(bf16_to_f32(dy[i]) * (cdf + x * pdf));
+    }
+}
+// SwiGLU: act = silu(g) u with the gate / up pre-activations in the GEMM's interleaved column order [16 g | 16 u]:
+// gu [rows, 2I], dact [rows, I] -> dgu [rows, 2I] in the same interleaved order (= the rows of the packed gate|up weight)
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact, bf16_t* __restrict__ dgu,
+                                                         long rows, int I) {
+    const long n = rows * I;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long row = i / I;
+        const int c = (int)(i - row * I), grp = c >> 4, in = c & 15;
+        const size_t o = (size_t)row * 2 * I + grp * 32 + in;
+        const float g = bf16_to_f32(gu[o]), u = bf16_to_f32(gu[o + 16]), d = bf16_to_f32(dact[i]);
+        const float sg = 1.f / (1.f + __expf(-g));
+        dgu[o] = f32_to_bf16(d * u * sg * (1.f + g * (1.f - sg)));
+        dgu[o + 16] = f32_to_bf16(d * g * sg);
+    }
+}
+// the SwiGLU forward on saved pre-activations (training path)
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, long rows, int I) {
+    const long n = rows * I;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long row = i / I;
+        const int c = (int)(i - row * I), grp = c >> 4, in = c & 15;
+        const size_t o = (size_t)row * 2 * I + grp * 32 + in;
+        act[i] = f32_to_bf16(act_silu(bf16_to_f32(gu[o])) * bf16_to_f32(gu[o + 16]));
+    }
+}
+
+// RoPE backward + re-assembly of the fused-QKV gradient: dqkv[row][Hq*D | Hkv*D | Hkv*D] from dq [rows, Hq, D] (gradient of the
+// ROTATED queries), dk / dv [B, Hkv, Sk_ld, D] fp32 (gradient of the rotated keys / of the values, per cache position).
+// The rotation is orthogonal: d(pre) = d(post) cos - rot_half(d(post)) sin   (hf:models/mistral/modeling_mistral.py:51-81 transposed)
+__global__ __launch_bounds__(256) void rope_bwd_assemble_kernel(const bf16_t* __restrict__ dq, const float* __restrict__ dk, const float* __restrict__ dv,
+                                                                bf16_t* __restrict__ dqkv, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                                const int* __restrict__ pos, int B, int S, int Hq, int Hkv, int D, int Sk_ld) {
+    const int QKV = (Hq + 2 * Hkv) * D, half = D >> 1;
+    const long n = (long)B * S * (Hq + 2 * Hkv) * half;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int d = (int)(i % half);
+        long t = i / half;
+        const int head = (int)(t % (Hq + 2 * Hkv));
+        const long row = t / (Hq + 2 * Hkv);
+        const int b = (int)(row / S), s = (int)(row - (long)b * S);
+        bf16_t* out = dqkv + row * QKV + (size_t)head * D;
+        if (head >= Hq + Hkv) {                 // V: no rotation
+            const float* src = dv + (((size_t)b * Hkv + (head - Hq - Hkv)) * Sk_ld + s) * D;
+            out[d] = f32_to_bf16(src[d]); out[d + half] = f32_to_bf16(src[d + half]);
+            continue;
+        }
+        float a, bb;
+        if (head < Hq) { const bf16_t* src = dq + (row * Hq + head) * D; a = bf16_to_f32(src[d]); bb = bf16_to_f32(src[d + half]); }
+        else { const float* src = dk + (((size_t)b * Hkv + (head - Hq)) * Sk_ld + s) * D; a = src[d]; bb = src[d + half]; }
+        const int p = pos[row];
+        const float c = cosT[(size_t)p * half + d], sn = sinT[(size_t)p * half + d];
+        // forward: y1 = x1 c - x2 s, y2 = x2 c + x1 s  ->  dx1 = dy1 c + dy2 s, dx2 = dy2 c - dy1 s
+        out[d] = f32_to_bf16(a * c + bb * sn);
+        out[d + half] = f32_to_bf16(bb * c - a * sn);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// causal-LM cross-entropy (hf:loss/loss_utils.py ForCausalLMLoss: fp32 logits, shift by one, ignore_index -100, mean over the
+// valid targets): row r = (b, s) is scored against label[b][s + 1]; loss_rows[r] = lse - logit[target] (0 when ignored);
+// dlogits[r][:] = (softmax - onehot) * inv_n (bf16, zero row when ignored, zero padding up to ldd).  One workgroup per row.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, int V, const int* __restrict__ labels, int S,
+                                                            float inv_n, float* __restrict__ loss_rows, bf16_t* __restrict__ dlogits, int ldd) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const int s = (int)(row % S), t = threadIdx.x;
+    const int target = s + 1 < S ? labels[row + 1] : -100;
+    bf16_t* d = dlogits + row * ldd;
+    if (target < 0 || target >= V) {
+        for (int j = t; j < ldd; j += 256) d[j] = 0;
+        if (t == 0) loss_rows[row] = 0.f;
+        return;
+    }
+    const float* l = logits + row * V;
+    float m = -INFINITY;
+    for (int j = t; j < V; j += 256) m = fmaxf(m, l[j]);
+    m = wave_max(m);
+    if ((t & 63) == 0) red[t >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = t; j < V; j += 256) sum += __expf(l[j] - m);
+    sum = block_sum_256(sum, red);
+    const float inv = inv_n / sum;
+    for (int j = t; j < ldd; j += 256) d[j] = j < V ? f32_to_bf16((__expf(l[j] - m) * inv) - (j == target ? inv_n : 0.f)) : (bf16_t)0;
+    if (t == 0) loss_rows[row] = (m + logf(sum)) - l[target];
+}
+
+// out[c] += sum_r y[r][c]   (bias gradients).  Stage 1: workgroup (x, g) adds rows g, g + G, ... of its 256 columns (512-byte row
+// pieces) into part[g][c]; stage 2 adds the G partials in order.
+__global__ __launch_bounds__(256) void colsum_part_kernel(const bf16_t* __restrict__ y, int ld, long rows, int cols, float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (long r = blockIdx.y; r < rows; r += gridDim.y) s += bf16_to_f32(y[r * ld + c]);
+    part[(size_t)blockIdx.y * cols + c] = s;
+}
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int G, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += part[(size_t)g * cols + c];
+    out[c] += s;
+}
+
+// rows of `src` picked by idx (>= 0) -> dst; dst[r] = 0 where idx[r] < 0   (visual-token rows out of d(inputs_embeds))
+__global__ __launch_bounds__(256) void gather_rows_idx_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx, bf16_t* __restrict__ dst,
+                                                              long rows, int cols) {
+    const int per_row = cols >> 3;
+    const long n = rows * per_row;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / per_row;
+        const int c = (int)(i - r * per_row) * 8;
+        const int j = idx[r];
+        u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (j >= 0) v = *(const u16x8*)(src + (size_t)j * cols + c);
+        *(u16x8*)(dst + r * cols + c) = v;
+    }
+}
+
+// dst[r] (+)= sum of src rows: dst [n_dst, cols] bf16 <- for every r: sum over k < n_src with map[k] == r of src[k]   (block 0 of the
+// Q-Former runs once per SAMPLE: the gradient of a sample's 32 rows is the sum over its tiles).  Small: one thread per element.
+__global__ __launch_bounds__(256) void segment_sum_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ map, int n_src, int rows_per,
+                                                               bf16_t* __restrict__ dst, int n_dst, int cols) {
+    const long n = (long)n_dst * rows_per * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cols);
+        const long t = i / cols;
+        const int q = (int)(t % rows_per), r = (int)(t / rows_per);
+        float s = 0.f;
+        for (int k = 0; k < n_src; ++k) if (map[k] == r) s += bf16_to_f32(src[((size_t)k * rows_per + q) * cols + c]);
+        dst[i] = f32_to_bf16(s);
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_f32_kernel(float* __restrict__ y, const float* __restrict__ x, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += x[i];
+}
+__global__ __launch_bounds__(256) void add_bf16_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = f32_to_bf16(bf16_to_f32(y[i]) + bf16_to_f32(x[i]));
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = bf16_to_f32(x[i]);
+}
+// out[q][c] += sum_b src[b * stride + q * cols + c]   (fp32 accumulation of a few bf16 row blocks: the learned_queries gradient)
+__global__ __launch_bounds__(256) void acc_rows_f32_kernel(float* __restrict__ out, const bf16_t* __restrict__ src, int n_batches, long stride, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int b = 0; b < n_batches; ++b) s += bf16_to_f32(src[(size_t)b * stride + i]);
+        out[i] += s;
+    }
+}
+__global__ __launch_bounds__(256) void f32_rows_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = f32_to_bf16(x[i]);
+}
+
+// torch.optim.AdamW (no amsgrad), one tensor: fp32 master / moments / gradient; writes the engine's working copy (bf16 matrix or
+// fp32 vector) and clears the gradient for the next accumulation.  hf Trainer: betas 0.9 / 0.999, eps 1e-8 (ref:script/pretrain.sh:39-42)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float* __restrict__ g,
+                                                    void* __restrict__ work, int work_bf16, long n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        p[i] = pi; m[i] = mi; v[i] = vi; g[i] = 0.f;
+        if (work_bf16) ((bf16_t*)work)[i] = f32_to_bf16(pi); else ((float*)work)[i] = pi;
+    }
+}
+
+inline int grid_for(long n, int cap = 8192) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
+
+}  // namespace
+
+int vz_launch_transpose(const bf16_t* src, long src_rs, long src_so, long src_si, bf16_t* dst, long dst_rs, long dst_so, long dst_si, int R,
+                        int C, int n_outer, int n_inner, int col0, hipStream_t s) {
+    VZ_CHECK_ARG(src && dst && R > 0 && C > 0 && n_outer > 0 && n_inner > 0 && (long)n_outer * n_inner <= 65535, "transpose: bad argument");
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, n_outer * n_inner), dim3(256), 0, s, src, src_rs, src_so, src_si, dst,
+                       dst_rs, dst_so, dst_si, R, C, n_inner, col0);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_softmax_fwd(const float* S, int lds_, bf16_t* P, int ldp, long rows, int H, int Sq, int Sk, float scale, int causal, int window,
+                          const int* kv_len, hipStream_t s) {
+    VZ_CHECK_ARG(S && P && rows > 0 && Sk <= lds_ && Sk <= ldp, "softmax_fwd: bad argument");
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, S, lds_, P, ldp, rows, H, Sq, Sk, scale, causal, window, kv_len);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_softmax_bwd(const bf16_t* P, int ldp, const float* dP, int lddp, bf16_t* dS, int ldds, long rows, int Sk, float scale, hipStream_t s) {
+    VZ_CHECK_ARG(P && dP && dS && rows > 0, "softmax_bwd: bad argument");
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, P, ldp, dP, lddp, dS, ldds, rows, Sk, scale);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_rmsnorm_bwd(const bf16_t* x, const float* w, const bf16_t* dy, const bf16_t* dres, bf16_t* dx, long rows, int cols, float eps,
+                          hipStream_t s) {
+    VZ_CHECK_ARG(x && w && dy && dx && rows > 0 && cols > 0, "rmsnorm_bwd: bad argument");
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, x, w, dy, dres, dx, rows, cols, eps);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+// `part` holds G * 2 * cols floats, G = vz_layernorm_bwd_groups(rows)
+int vz_layernorm_bwd_groups(long rows) { return (int)(rows < 512 ? rows : 512); }
+int vz_launch_layernorm_bwd(const bf16_t* x, const float* w, const bf16_t* dy, const bf16_t* dres, bf16_t* dx, float* part, float* dw, float* db,
+                            long rows, int cols, float eps, hipStream_t s) {
+    VZ_CHECK_ARG(x && w && dy && part && dw && db && rows > 0 && cols > 0 && cols <= LN_MAX_PER_THREAD * 256, "layernorm_bwd: bad argument (cols <= %d)", LN_MAX_PER_THREAD * 256);
+    const int G = vz_layernorm_bwd_groups(rows);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(G), dim3(256), 0, s, x, w, dy, dres, dx, part, rows, cols, eps);
+    VZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * cols + 255) / 256), dim3(256), 0, s, part, G, cols, dw, db);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_gelu_fwd(const bf16_t* h, bf16_t* y, long n, hipStream_t s) {
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, h, y, n);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_gelu_bwd(const bf16_t* h, const bf16_t* dy, bf16_t* dh, long n, hipStream_t s) {
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, h, dy, dh, n);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_swiglu_fwd(const bf16_t* gu, bf16_t* act, long rows, int I, hipStream_t s) {
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * I)), dim3(256), 0, s, gu, act, rows, I);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_swiglu_bwd(const bf16_t* gu, const bf16_t* dact, bf16_t* dgu, long rows, int I, hipStream_t s) {
+    VZ_CHECK_ARG(I % 16 == 0, "swiglu_bwd: I %% 16");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * I)), dim3(256), 0, s, gu, dact, dgu, rows, I);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_rope_bwd_assemble(const bf16_t* dq, const float* dk, const float* dv, bf16_t* dqkv, const float* cosT, const float* sinT, const int* pos,
+                                int B, int S, int Hq, int Hkv, int D, int Sk_ld, hipStream_t s) {
+    hipLaunchKernelGGL(rope_bwd_assemble_kernel, dim3(grid_for((long)B * S * (Hq + 2 * Hkv) * (D / 2))), dim3(256), 0, s, dq, dk, dv, dqkv, cosT, sinT,
+                       pos, B, S, Hq, Hkv, D, Sk_ld);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_cross_entropy(const float* logits, int V, const int* labels, long rows, int S, float inv_n, float* loss_rows, bf16_t* dlogits, int ldd,
+                            hipStream_t s) {
+    VZ_CHECK_ARG(logits && labels && loss_rows && dlogits && rows > 0 && ldd >= V, "cross_entropy: bad argument");
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3((int)rows), dim3(256), 0, s, logits, V, labels, S, inv_n, loss_rows, dlogits, ldd);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+// `part`: vz_colsum_groups(rows) * cols floats of scratch
+int vz_colsum_groups(long rows) { return (int)(rows < 4096 ? (rows + 63) / 64 : 64); }
+int vz_launch_colsum(const bf16_t* y, int ld, long rows, int cols, float* part, float* out, hipStream_t s) {
+    VZ_CHECK_ARG(y && part && out && rows > 0 && cols > 0, "colsum: bad argument");
+    const int G = vz_colsum_groups(rows);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((cols + 255) / 256, G), dim3(256), 0, s, y, ld, rows, cols, part);
+    VZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, part, G, cols, out);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_gather_rows_idx(const bf16_t* src, const int* idx, bf16_t* dst, long rows, int cols, hipStream_t s) {
+    VZ_CHECK_ARG(cols % 8 == 0, "gather_rows_idx: cols %% 8");
+    hipLaunchKernelGGL(gather_rows_idx_kernel, dim3(grid_for(rows * (cols / 8))), dim3(256), 0, s, src, idx, dst, rows, cols);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_segment_sum_rows(const bf16_t* src, const int* map, int n_src, int rows_per, bf16_t* dst, int n_dst, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(grid_for((long)n_dst * rows_per * cols)), dim3(256), 0, s, src, map, n_src, rows_per, dst, n_dst, cols);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_axpy_f32(float* y, const float* x, long n, hipStream_t s) {
+    hipLaunchKernelGGL(axpy_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, x, n);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_add_bf16(bf16_t* y, const bf16_t* x, long n, hipStream_t s) {
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, x, n);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_bf16_to_f32(const bf16_t* x, float* y, long n, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_acc_rows_f32(float* out, const bf16_t* src, int n_batches, long stride, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(acc_rows_f32_kernel, dim3(grid_for((long)rows * cols)), dim3(256), 0, s, out, src, n_batches, stride, (long)rows * cols);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_f32_to_bf16(const float* x, bf16_t* y, long n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_rows_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+int vz_launch_adamw(float* p, float* m, float* v, float* g, void* work, int work_bf16, long n, float lr, float b1, float b2, float eps, float wd,
+                    int t, hipStream_t s) {
+    VZ_CHECK_ARG(p && m && v && g && work && n > 0 && t >= 1, "adamw: bad argument");
+    const float bc1 = 1.f - powf(b1, (float)t), bc2s = sqrtf(1.f - powf(b2, (float)t));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, m, v, g, work, work_bf16, n, lr, b1, b2, eps, wd, bc1, bc2s);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}

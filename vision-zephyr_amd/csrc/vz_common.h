@@ -152,6 +152,13 @@ inline void vz_launch_timed(F kernel, dim3 grid, dim3 block, size_t lds, hipStre
         hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
     }
 }
+struct BatchedGemmArgs {
+    const bf16_t* A; int lda; const bf16_t* W; int ldw; void* C; int ldc;
+    int M, N, K, out_fp32;
+    int n_outer, n_inner, a_div, w_div;
+    long a_so, a_si, w_so, w_si, c_so, c_si;       // element strides of the outer / inner batch index per operand
+};
+int vz_launch_gemm_batched(const BatchedGemmArgs& b, hipStream_t s);
 int vz_launch_gemv(const LinearArgs& a, hipStream_t s);
 int vz_launch_gemm128(const LinearArgs& a, hipStream_t s);
 int vz_launch_gemm256(const LinearArgs& a, hipStream_t s);
@@ -248,3 +255,34 @@ int vz_launch_copy_rows(const bf16_t* src, long src_stride, bf16_t* dst, long ds
                         hipStream_t s);
 int vz_launch_step_advance(int* step, hipStream_t s);
 int vz_launch_repack_logits(const float* gathered, float* out, int rows, int Vp, int V, int tp, hipStream_t s);
+
+// ---- backward kernels of the Stage-1 training step (train.hip) ----
+int vz_launch_transpose(const bf16_t* src, long src_rs, long src_so, long src_si, bf16_t* dst, long dst_rs, long dst_so, long dst_si, int R,
+                        int C, int n_outer, int n_inner, int col0, hipStream_t s);
+int vz_launch_softmax_fwd(const float* S, int lds_, bf16_t* P, int ldp, long rows, int H, int Sq, int Sk, float scale, int causal, int window,
+                          const int* kv_len, hipStream_t s);
+int vz_launch_softmax_bwd(const bf16_t* P, int ldp, const float* dP, int lddp, bf16_t* dS, int ldds, long rows, int Sk, float scale, hipStream_t s);
+int vz_launch_rmsnorm_bwd(const bf16_t* x, const float* w, const bf16_t* dy, const bf16_t* dres, bf16_t* dx, long rows, int cols, float eps,
+                          hipStream_t s);
+int vz_layernorm_bwd_groups(long rows);
+int vz_launch_layernorm_bwd(const bf16_t* x, const float* w, const bf16_t* dy, const bf16_t* dres, bf16_t* dx, float* part, float* dw, float* db,
+                            long rows, int cols, float eps, hipStream_t s);
+int vz_launch_gelu_fwd(const bf16_t* h, bf16_t* y, long n, hipStream_t s);
+int vz_launch_gelu_bwd(const bf16_t* h, const bf16_t* dy, bf16_t* dh, long n, hipStream_t s);
+int vz_launch_swiglu_fwd(const bf16_t* gu, bf16_t* act, long rows, int I, hipStream_t s);
+int vz_launch_swiglu_bwd(const bf16_t* gu, const bf16_t* dact, bf16_t* dgu, long rows, int I, hipStream_t s);
+int vz_launch_rope_bwd_assemble(const bf16_t* dq, const float* dk, const float* dv, bf16_t* dqkv, const float* cosT, const float* sinT, const int* pos,
+                                int B, int S, int Hq, int Hkv, int D, int Sk_ld, hipStream_t s);
+int vz_launch_cross_entropy(const float* logits, int V, const int* labels, long rows, int S, float inv_n, float* loss_rows, bf16_t* dlogits, int ldd,
+                            hipStream_t s);
+int vz_colsum_groups(long rows);
+int vz_launch_colsum(const bf16_t* y, int ld, long rows, int cols, float* part, float* out, hipStream_t s);
+int vz_launch_gather_rows_idx(const bf16_t* src, const int* idx, bf16_t* dst, long rows, int cols, hipStream_t s);
+int vz_launch_segment_sum_rows(const bf16_t* src, const int* map, int n_src, int rows_per, bf16_t* dst, int n_dst, int cols, hipStream_t s);
+int vz_launch_axpy_f32(float* y, const float* x, long n, hipStream_t s);
+int vz_launch_add_bf16(bf16_t* y, const bf16_t* x, long n, hipStream_t s);
+int vz_launch_f32_to_bf16(const float* x, bf16_t* y, long n, hipStream_t s);
+int vz_launch_bf16_to_f32(const bf16_t* x, float* y, long n, hipStream_t s);
+int vz_launch_acc_rows_f32(float* out, const bf16_t* src, int n_batches, long stride, int rows, int cols, hipStream_t s);
+int vz_launch_adamw(float* p, float* m, float* v, float* g, void* work, int work_bf16, long n, float lr, float b1, float b2, float eps, float wd,
+                    int t, hipStream_t s);

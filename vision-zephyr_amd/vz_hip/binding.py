@@ -19,7 +19,7 @@ VZ_OK, VZ_ERR_ARG, VZ_ERR_HIP, VZ_ERR_STATE, VZ_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 VZ_ASYNC_FUSED, VZ_ASYNC_STREAMK = 1, 2
 ABI_VERSION = 5
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
-K_GEMM, K_GEMV, K_ATTN, K_ATTN_DEC, K_NORM, K_OTHER = range(6)
+K_GEMM, K_GEMV, K_ATTN, K_ATTN_DEC, K_NORM, K_OTHER, K_FUSED, K_COMM = range(8)
 
 
 class VzConfig(C.Structure):
@@ -85,6 +85,18 @@ SYMBOLS = {
     "vz_engine_unset_weight": (_I, [_P, C.c_char_p]),
     "vz_llm_decode_sampling": (_I, [_P, _I, _F, _I, _F, C.c_ulonglong, _I]),
     "vz_llm_decode_ring": (_I, [_P, _P, _I]),
+    "vz_train_create": (_I, [_P, C.POINTER(_P), _P]),
+    "vz_train_destroy": (_I, [_P]),
+    "vz_train_set_master": (_I, [_P, C.c_char_p, _P, _L, _P]),
+    "vz_train_param_count": (_I, [_P]),
+    "vz_train_param_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)]),
+    "vz_train_arenas": (_I, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_L)]),
+    "vz_train_stage1_accumulate": (_I, [_P, _P, _I, _P, _I, _I, C.POINTER(_I), _P, _P, _P, _I, _I, C.POINTER(_I), _P, _P, _F, _P]),
+    "vz_train_loss_sum": (_I, [_P, C.POINTER(C.c_double), _P]),
+    "vz_train_zero_grad": (_I, [_P, _P]),
+    "vz_train_comm_init": (_I, [_P, C.c_char_p, _I, _I]),
+    "vz_train_allreduce": (_I, [_P, _P]),
+    "vz_train_adamw_step": (_I, [_P, _F, _F, _F, _F, _F, _P]),
     "vz_op_vip_point": (_I, [_P, _I, _I, _I, _I, _I, _I, C.c_uint, _P]),
     "vz_op_sample": (_I, [_P, _I, _I, _F, _I, _F, C.c_ulonglong, _I, _P, _P]),
 }
