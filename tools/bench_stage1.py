@@ -3,7 +3,10 @@
 tensor parallelism: `forward` over 64 plain-caption samples x 5 anyres tiles (320 tiles), 40 ids each -> S = 39 + 160 = 199 rows
 per sample, labels in, loss + logits for all positions out.
 
-    python tools/bench_stage1.py [samples] [layers]
+    python tools/bench_stage1.py [samples] [layers]            forward only
+    python tools/bench_stage1.py [samples] [layers] train [mb]  the Stage-1 OPTIMISER STEP: forward with saved
+                                                                activations + backward (frozen Zephyr input gradients, all 165
+                                                                projector gradients) + AdamW, in micro-batches of mb samples (16)
 
 Prints the two halves (tiles -> visual tokens -> spliced embeddings; Zephyr forward + loss) and the algorithmic TFLOP/s of each
 (CLIP 381.9 GFLOP per tile, Q-Former 59.4 x 8 GFLOP per tile for its 32-row blocks + the cross-attention K/V projections,
@@ -23,6 +26,8 @@ from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM  # noqa: E402
 nums = [int(a) for a in sys.argv[1:] if a.isdigit()]
 Bn = nums[0] if nums else 64
 layers = nums[1] if len(nums) > 1 else 32
+TRAIN = "train" in sys.argv[1:]
+MB = nums[2] if len(nums) > 2 else 16
 N_TILES, N_IDS = 5, 40
 S = N_IDS - 1 + 32 * N_TILES
 
@@ -57,9 +62,32 @@ def run():
     return t1 - t0, t2 - t1
 
 
+T = Bn * N_TILES
+if TRAIN:
+    from vz_hip.train import Stage1Trainer
+    tr = Stage1Trainer(model)
+    arch = model.arch
+    per_layer_w = ((arch.n_heads + 2 * arch.n_kv_heads) * arch.head_dim + arch.hidden + 3 * arch.inter) * arch.hidden
+    f_clip, f_qf = 381.9e9 * T, (8 * 59.4e9) * T
+    f_lin = Bn * (2 * S * layers * per_layer_w + 2 * S * arch.vocab * arch.hidden)
+    f_att = Bn * layers * 4 * S * S * arch.hidden / 2
+    # step = forward + Zephyr input gradients (1 x its linears, 2.5 x its attention) + Q-Former backward (2 x: weight + input gradients)
+    f_step = f_clip + 3 * f_qf + 2 * f_lin + 3.5 * f_att
+    losses, times = [], []
+    for it in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses.append(tr.step(ids, mask, labels, tiles, lr=2e-5, micro_batch=MB))
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    print(f"stage-1 optimiser step: {Bn} samples x {N_TILES} tiles, S={S}, {layers} layers, micro-batches of {MB}, one GPU")
+    print(f"  losses over 4 steps on the same batch: {' '.join(f'{v:.4f}' for v in losses)}")
+    print(f"  step time: {best * 1e3:8.1f} ms  ({Bn / best:6.1f} samples/s, {f_step / best / 1e12:6.1f} TFLOP/s algorithmic = {f_step / best / 2.5e15 * 100:4.1f} % of 2.5 PF; "
+          f"first step incl. allocations {times[0] * 1e3:.0f} ms)")
+    sys.exit(0)
 run()
 enc, llm = min((run() for _ in range(3)), key=sum)
-T = Bn * N_TILES
 arch = model.arch
 per_layer_w = ((arch.n_heads + 2 * arch.n_kv_heads) * arch.head_dim + arch.hidden + 3 * arch.inter) * arch.hidden
 f_clip = 381.9e9 * T
