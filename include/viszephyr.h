@@ -78,7 +78,7 @@ int vz_op_linear_fp8(const void* d_A, int lda, const void* d_W8, int ldw, const 
 int vz_op_linear_rmsnorm(const void* d_A, int lda, const float* d_norm_w, float norm_eps, const void* d_W, int ldw, void* d_C, int ldc,
                          int M, int N, int K, const void* d_residual, int ldr, int act, int out_fp32, vz_stream stream);
 /* same contract, forcing one implementation (tests): impl 0 = 128^2 MFMA tile GEMM, 1 = GEMV (M <= 8), 2 = 256^2 tile GEMM,
- * 3 = MFMA weight stream for 2 <= M <= 64 (batched decode) */
+ * 3 = MFMA weight stream for 2 <= M <= 64 (batched decode), 4 = the 128^2 tile GEMM with the finer split-K of the 17..64-row decode route */
 int vz_op_linear_impl(int impl, const void* d_A, int lda, const void* d_W, int ldw, void* d_C, int ldc,
                       int M, int N, int K, const float* d_bias, const void* d_residual, int ldr,
                       int act, int out_fp32, vz_stream stream);
@@ -325,7 +325,7 @@ int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_strea
  * 2 = prefill attention generation, 3 = split-K mode, 4 = 256^2 GEMM stream-K tail (1 = on, 0 = whole tiles only), 5 = stream-K skew in K-tiles, 6 = record 256^2 GEMM phase stamps,
  * 7 = route the collectives of a tp_size == 1 engine that holds a one-rank communicator through RCCL (self-test),
  * 9 = 2..16-row linears (1 = MFMA weight stream, 0 = GEMV / tile GEMM), 10 = context splits of the fused decode attention
- * (0 = engine default, 1..64), 13 = record role stamps of that launch, 12 = one launch for QKV GEMV + attention + O GEMV of a batch-1 decode layer (1 = on; default 0), 11 = 256^2 GEMM workgroups wait for their epilogue stores before they end (experiment; 0 = off).
+ * (0 = engine default, 1..64), 13 = record role stamps of that launch, 15 = split-K factor of the K = 4096 projections on that route (default 8), 14 = rows from which a decode step's linears run on the 128^2 tile GEMM (default 25; 65 = never), 12 = one launch for QKV GEMV + attention + O GEMV of a batch-1 decode layer (1 = on; default 0), 11 = 256^2 GEMM workgroups wait for their epilogue stores before they end (experiment; 0 = off).
  * Process-wide. */
 int vz_tune_set(int knob, int value);
 

@@ -739,3 +739,20 @@ def test_gemm256_streamk_expired_wait_raises_and_poisons(B):
         assert torch.equal(again, good) and B.op_async_error() == 0
     finally:
         B.check(B.lib().vz_tune_set(4, 1))
+
+
+@pytest.mark.parametrize("M,N,K,act", [(33, 6144, 4096, 0), (64, 4096, 4096, 0), (48, 4096, 14336, 0), (64, 28672, 4096, 3), (40, 3584, 4096, 3),
+                                       (64, 32000, 4096, 0)])
+def test_decode_tile_route_splitk(B, M, N, K, act):
+    """33..64-row decode steps run their linears on the 128^2 tile GEMM with a finer split-K (impl 4): QKV / O x8, down x16, gate|up x2
+    with the SwiGLU pairs formed by the finalize kernel.  Against the fp64 reference and the un-split tile GEMM, with residual."""
+    x = _rand((M, K), 1.0, 401).bfloat16()
+    w = _rand((N, K), 0.03, 402).bfloat16()
+    n_out = N // 2 if act == 3 else N
+    res = _rand((M, n_out), 0.5, 403).bfloat16()
+    out = B.linear(x, w, residual=res, act=act, out_fp32=True, impl=4)
+    check_close(f"decode tile route M{M} N{N} K{K} act{act}", out, _ref_linear(x, w, None, res, act), 1e-4, 1e-4)
+    check_close("vs whole-K tile GEMM", out, B.linear(x, w, residual=res, act=act, out_fp32=True, impl=0), 2e-5, 2e-5)
+    o16 = B.linear(x, w, residual=res, act=act, impl=4)
+    check_close("bf16 out", o16, _ref_linear(x, w, None, res, act), BF16_MAX, BF16_L2)
+    assert torch.equal(B.linear(x, w, residual=res, act=act, out_fp32=True, impl=4), out)

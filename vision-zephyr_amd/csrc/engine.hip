@@ -53,6 +53,22 @@ static LinearArgs mk_linear(const void* A, int lda, const void* W, int ldw, void
     return a;
 }
 
+// vz_tune_set(14, rows): from this many rows on a decode step's linears run on the 128^2 tile GEMM (65 = never)
+static int g_decode_tile_rows = 25;      // measured cross-over (profiles/r02_rows.txt): the tile route costs ~5.2 ms per step from 25 to 48 rows, the MFMA weight stream 5.25 at 24 and 5.79 at 32
+static int g_decode_sk_short = 8;      // vz_tune_set(15, v): split-K factor of the K = 4096 decode projections (QKV, O) on the tile-GEMM route
+static int vz_decode_splitk(int N, int K, int act) {
+    // In situ (rocprofv3 of a 64-row step, profiles/r02_rows.txt) the 128^2 kernel is bound by the bytes its workgroups keep in flight
+    // (32 KiB each): gate|up with 224 workgroups ran at 3.3 TB/s, down with 512 (split 16) at 4.4.  So every projection is cut along K
+    // until ~2 workgroups per CU are streaming: gate|up x2 (the SwiGLU pairs are formed by the finalize kernel), QKV / O x8, down x16.
+    if (N & 7) return 0;
+    const int tiles_n = (N + 127) / 128;
+    if (act == VZ_ACT_SWIGLU) return tiles_n < 384 ? 2 : 0;
+    if (K < 8192) return g_decode_sk_short;
+    int sk = (512 + tiles_n - 1) / tiles_n;
+    if (sk > 16) sk = 16;
+    return sk < 1 ? 1 : sk;
+}
+
 extern "C" int vz_op_linear(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                             const float* bias, const void* residual, int ldr, int act, int out_fp32, vz_stream s) {
     return vz_launch_linear(mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, act, out_fp32), (hipStream_t)s);
@@ -81,6 +97,7 @@ extern "C" int vz_op_linear_impl(int impl, const void* A, int lda, const void* W
     if (impl == 1) return vz_launch_gemv(a, (hipStream_t)s);
     if (impl == 2) return vz_launch_gemm256(a, (hipStream_t)s);
     if (impl == 3) return vz_launch_skinny(a, (hipStream_t)s);
+    if (impl == 4) { a.splitk_hint = vz_decode_splitk(N, K, act); return vz_launch_gemm128(a, (hipStream_t)s); }     // the 17..64-row decode route
     vz_set_error("linear: unknown impl %d", impl);
     return VZ_ERR_ARG;
 }
@@ -245,6 +262,22 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
         LinearArgs t = a;
         if (M > 16) t.norm_w = nullptr;   // 17..32 rows: the norm runs as its own kernel below
         if (!vz_gemv_ok(t) && !(g_skinny_mode && vz_skinny_ok(t))) { a.W8 = nullptr; a.wscale = nullptr; }
+    }
+    if (klass_hint == 1 && M >= ((W8 && ws) ? std::max(g_decode_tile_rows, 33) : g_decode_tile_rows) && M <= 64 && g_skinny_mode && (K & 63) == 0) {     // (e4m3 stream: ahead up to 32 rows)
+        // 17..64-row decode step as a TILE GEMM: the 128^2 MFMA kernel streams every weight once at the rate its workgroups can pull
+        // (gate-up 48 us = 4.9 TB/s whatever the row count), where the MFMA weight stream of gemm_skinny.hip re-reads the activations
+        // per 16-row group and falls to 2.7 TB/s at 64 rows (tools/bench_rows.py, profiles/r02_rows.txt).  Projections with few column
+        // tiles (QKV 48, O / down 32) are cut along K until ~512 workgroups are in flight.  The RMSNorm runs as its own launch.
+        if (norm_w) {
+            ProfScope ps(e, K_NORM, s);
+            int r = vz_launch_rmsnorm(A, lda, e->d_xnorm, K, norm_w, M, K, norm_eps, s);
+            if (r) return r;
+            a.A = e->d_xnorm; a.lda = K; a.norm_w = nullptr;
+        }
+        a.W8 = nullptr; a.wscale = nullptr;          // (a weight_fp8 engine's bf16 tensors hold the same dequantised values)
+        a.splitk_hint = vz_decode_splitk(N, K, act);
+        ProfScope ps(e, K_GEMV, s);
+        return vz_launch_gemm128(a, s);
     }
     if (norm_w && M > 4 && M <= 64 && K == e->c.hidden && g_skinny_mode && !(vz_skinny_ok(a) && vz_skinny_fused_norm_ok(a))) {
         // 5..16 rows without the persistent fused-norm kernel (knob 9 = 2, or a K it does not take): normalise once into an
@@ -1147,6 +1180,8 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 9) { g_skinny_mode = value; return VZ_OK; }
     if (knob == 11) { g_gemm256_drain = value; return VZ_OK; }
     if (knob == 12) { g_decode_fuse = value; return VZ_OK; }
+    if (knob == 14) { g_decode_tile_rows = value; return VZ_OK; }
+    if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 13) { g_decode_fuse_stamps = value; return VZ_OK; }
     if (knob == 10) { if (value < 0 || value > 64) { vz_set_error("tune_set: decode attention splits must be 0..64"); return VZ_ERR_ARG; } g_attn_nsplit = value; return VZ_OK; }
     vz_set_error("tune_set: unknown knob %d", knob);

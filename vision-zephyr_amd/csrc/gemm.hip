@@ -280,21 +280,41 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
-// sum of the split-K slabs + the fused epilogue (bias / activation / residual / bf16|fp32 out), 4 outputs per thread
+// sum of the split-K slabs + the fused epilogue (bias / activation / residual / bf16|fp32 out), 4 outputs per thread.
+// SwiGLU (decode batches of 33..64 rows cut the gate|up GEMM in two along K): the slabs hold the raw [M, N = 2I] sums in the
+// interleaved [16 gate | 16 up] column order; output column c of [M, I] pairs slab columns (c >> 4) * 32 + (c & 15) and + 16.
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmParams p) {
-    const long quads = (long)p.M * (p.N / 4);
+    const bool swiglu = p.act == VZ_ACT_SWIGLU;
+    const int n_out = swiglu ? p.N / 2 : p.N;
+    const long quads = (long)p.M * (n_out / 4);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < quads; i += (long)gridDim.x * 256) {
-        const int m = (int)(i / (p.N / 4)), n0 = (int)(i % (p.N / 4)) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int s2 = 0; s2 < p.splitk; ++s2) v += *(const f32x4*)(p.slab + ((size_t)s2 * p.M + m) * p.N + n0);
+        const int m = (int)(i / (n_out / 4)), n0 = (int)(i % (n_out / 4)) * 4;
         float o[4];
+        if (swiglu) {
+            const int gc = (n0 >> 4) * 32 + (n0 & 15);
+            f32x4 g = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
+            for (int s2 = 0; s2 < p.splitk; ++s2) {
+                const float* row = p.slab + ((size_t)s2 * p.M + m) * p.N;
+                g += *(const f32x4*)(row + gc);
+                u += *(const f32x4*)(row + gc + 16);
+            }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float t = v[j];
-            if (p.bias) t += p.bias[n0 + j];
-            t = apply_act(t, p.act);
-            if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + n0 + j]);
-            o[j] = t;
+            for (int j = 0; j < 4; ++j) {
+                float t = act_silu(g[j]) * u[j];
+                if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + n0 + j]);
+                o[j] = t;
+            }
+        } else {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int s2 = 0; s2 < p.splitk; ++s2) v += *(const f32x4*)(p.slab + ((size_t)s2 * p.M + m) * p.N + n0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = v[j];
+                if (p.bias) t += p.bias[n0 + j];
+                t = apply_act(t, p.act);
+                if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + n0 + j]);
+                o[j] = t;
+            }
         }
         if (p.out_fp32) {
             float* c = (float*)p.C + (size_t)m * p.ldc + n0;
@@ -385,6 +405,12 @@ int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
         if (splitk > 4) splitk = 4;
         while (splitk > 1 && nk / splitk < 8) --splitk;
     }
+    if (a.splitk_hint > 0 && (a.N & 7) == 0) {       // decode batches (see LinearArgs.splitk_hint); SwiGLU pairs are formed in the finalize kernel
+        splitk = a.splitk_hint;
+        while (splitk > 1 && nk / splitk < 4) --splitk;
+        // this route runs inside the captured decode graph: the slab never grows there (96 MiB up front covers 64 rows x 8 slices of the lm_head)
+        while (splitk > 1 && (size_t)splitk * a.M * a.N * sizeof(float) > g_slab_bytes) --splitk;
+    }
     p.splitk = splitk; p.slab = nullptr; p.n_inner = 0; p.a_div = p.w_div = 1; p.a_so = p.a_si = p.w_so = p.w_si = p.c_so = p.c_si = 0;
     if (splitk > 1) {
         const size_t need = (size_t)splitk * a.M * a.N * sizeof(float);
@@ -398,7 +424,7 @@ int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
     vz_launch_timed(gemm_bf16_kernel, dim3(tiles * splitk), dim3(256), GEMM_LDS, s, p);
     VZ_LAUNCH_CHECK();
     if (splitk > 1) {
-        long blocks = ((long)a.M * (a.N / 4) + 255) / 256;
+        long blocks = ((long)a.M * ((a.act == VZ_ACT_SWIGLU ? a.N / 2 : a.N) / 4) + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_finalize_kernel, dim3((int)blocks), dim3(256), 0, s, p);
         VZ_LAUNCH_CHECK();

@@ -125,6 +125,9 @@ struct LinearArgs {
     // Q-Former linears: there a row's result must not depend on how many rows sit beside it (the tile GEMM's split-K is a
     // function of N and K only; tests/test_stages_gpu.py::test_qformer), and 32 / 64 / 96 rows must all take the same kernel.
     bool wide_ok = true;
+    // 128^2 tile GEMM only: split-K factor to use instead of the batch-invariant default (0 = default).  A decode batch of 17..64 rows
+    // (independent sequences, weight-stream bound) cuts K finer so that N / 128 column tiles fill the 256 CUs
+    int splitk_hint = 0;
     // async error word of the caller (an engine's); nullptr = the launch stream's own (vz_op_async_error)
     int* err = nullptr;
 };
