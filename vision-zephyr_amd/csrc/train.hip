@@ -126,67 +126,75 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // LayerNorm backward with parameter gradients (torch.nn.LayerNorm of the Q-Former, ref:...multimodal_projector/builder.py:14-27,68-70).
-// Workgroup g takes rows g, g + G, ...; thread t owns columns t, t + 256, ... (<= 20 of them: cols <= 5120) and keeps their dw / db
-// partial sums in registers across its rows; written to part[g][2][cols] at the end and added by layernorm_bwd_reduce_kernel in
-// workgroup order.  dx (optional) = rstd (g - mean(g) - xh mean(g xh)) [+ dres], g = dy w.
+//   xh = (x - mean) rstd, g = dy w:   dx = rstd (g - mean(g) - xh mean(g xh)) [+ dres];   dw = sum_rows dy xh;   db = sum_rows dy
+// Two kernels (round 2, second form: the first - one workgroup per row with four block reductions - took 1.7 ms per call, 13.5 % of the
+// Stage-1 step, profiles/r02_train_kernel_stats.txt):
+//   ln_bwd_dx_kernel    one WAVE per row (the 8-10 KiB row is re-read from L1 for each of its four sums: no LDS, no barrier); writes dx
+//                       (optional) and the row's (mean, rstd) for the second kernel
+//   ln_bwd_dwdb_kernel  thread = one column, workgroup (x, g) walks rows g, g + G, ... (512-byte coalesced row pieces) accumulating
+//                       dw / db in registers -> part[g][2][cols], added in workgroup order by layernorm_bwd_reduce_kernel (no float
+//                       atomics: gradients are reproducible bit for bit)
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int LN_MAX_PER_THREAD = 20;
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const bf16_t* __restrict__ dy,
-                                                            const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, float* __restrict__ part,
-                                                            long rows, int cols, float eps) {
-    __shared__ float red[4];
-    const int t = threadIdx.x, per = (cols + 255) / 256;
-    float dwp[LN_MAX_PER_THREAD], dbp[LN_MAX_PER_THREAD];
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const bf16_t* __restrict__ dy,
+                                                        const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, float* __restrict__ stats,
+                                                        long rows, int cols, float eps) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const bf16_t* xr = x + row * cols;
+    const bf16_t* gr = dy + row * cols;
+    float s = 0.f;
+    for (int c = lane * 8; c < cols; c += 512) {
+        const u16x8 v = *(const u16x8*)(xr + c);
 #pragma unroll
-    for (int k = 0; k < LN_MAX_PER_THREAD; ++k) { dwp[k] = 0.f; dbp[k] = 0.f; }
-    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-        const bf16_t* xr = x + row * cols;
-        const bf16_t* gr = dy + row * cols;
-        float xv[LN_MAX_PER_THREAD], gv[LN_MAX_PER_THREAD];
-        float s = 0.f;
+        for (int j = 0; j < 8; ++j) s += bf16_to_f32(v[j]);
+    }
+    const float mean = wave_sum(s) / cols;
+    float vs = 0.f;
+    for (int c = lane * 8; c < cols; c += 512) {
+        const u16x8 v = *(const u16x8*)(xr + c);
 #pragma unroll
-        for (int k = 0; k < LN_MAX_PER_THREAD; ++k) {
-            const int c = t + k * 256;
-            const bool in = k < per && c < cols;
-            xv[k] = in ? bf16_to_f32(xr[c]) : 0.f;
-            gv[k] = in ? bf16_to_f32(gr[c]) : 0.f;
-            s += xv[k];
-        }
-        const float mean = block_sum_256(s, red) / cols;
-        float vs = 0.f;
+        for (int j = 0; j < 8; ++j) { const float d = bf16_to_f32(v[j]) - mean; vs += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(vs) / cols + eps);
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    if (!dx) return;
+    float sg = 0.f, sgx = 0.f;
+    for (int c = lane * 8; c < cols; c += 512) {
+        const u16x8 xv = *(const u16x8*)(xr + c), gv = *(const u16x8*)(gr + c);
 #pragma unroll
-        for (int k = 0; k < LN_MAX_PER_THREAD; ++k) { const int c = t + k * 256; if (k < per && c < cols) { const float d = xv[k] - mean; vs += d * d; } }
-        const float rstd = rsqrtf(block_sum_256(vs, red) / cols + eps);
-        float sg = 0.f, sgx = 0.f;
-#pragma unroll
-        for (int k = 0; k < LN_MAX_PER_THREAD; ++k) {
-            const int c = t + k * 256;
-            if (k < per && c < cols) {
-                const float xh = (xv[k] - mean) * rstd, g = gv[k] * w[c];
-                xv[k] = xh;
-                sg += g; sgx += g * xh;
-                dwp[k] += gv[k] * xh; dbp[k] += gv[k];
-            }
-        }
-        if (dx) {                  // (uniform over the workgroup)
-            const float mg = block_sum_256(sg, red) / cols, mgx = block_sum_256(sgx, red) / cols;
-#pragma unroll
-            for (int k = 0; k < LN_MAX_PER_THREAD; ++k) {
-                const int c = t + k * 256;
-                if (k < per && c < cols) {
-                    float v = rstd * (gv[k] * w[c] - mg - xv[k] * mgx);
-                    if (dres) v += bf16_to_f32(dres[row * cols + c]);
-                    dx[row * cols + c] = f32_to_bf16(v);
-                }
-            }
+        for (int j = 0; j < 8; ++j) {
+            const float g = bf16_to_f32(gv[j]) * w[c + j];
+            sg += g; sgx += g * (bf16_to_f32(xv[j]) - mean) * rstd;
         }
     }
-    float* pw = part + (size_t)blockIdx.x * 2 * cols;
+    const float mg = wave_sum(sg) / cols, mgx = wave_sum(sgx) / cols;
+    for (int c = lane * 8; c < cols; c += 512) {
+        const u16x8 xv = *(const u16x8*)(xr + c), gv = *(const u16x8*)(gr + c);
+        u16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (dres) rv = *(const u16x8*)(dres + row * cols + c);
+        u16x8 o;
 #pragma unroll
-    for (int k = 0; k < LN_MAX_PER_THREAD; ++k) {
-        const int c = t + k * 256;
-        if (k < per && c < cols) { pw[c] = dwp[k]; pw[cols + c] = dbp[k]; }
+        for (int j = 0; j < 8; ++j) {
+            float v = rstd * (bf16_to_f32(gv[j]) * w[c + j] - mg - (bf16_to_f32(xv[j]) - mean) * rstd * mgx);
+            if (dres) v += bf16_to_f32(rv[j]);
+            o[j] = f32_to_bf16(v);
+        }
+        *(u16x8*)(dx + row * cols + c) = o;
     }
+}
+__global__ __launch_bounds__(256) void ln_bwd_dwdb_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ stats,
+                                                          float* __restrict__ part, long rows, int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float dw = 0.f, db = 0.f;
+    for (long r = blockIdx.y; r < rows; r += gridDim.y) {
+        const float g = bf16_to_f32(dy[r * cols + c]);
+        dw += g * (bf16_to_f32(x[r * cols + c]) - stats[2 * r]) * stats[2 * r + 1];
+        db += g;
+    }
+    float* pw = part + (size_t)blockIdx.y * 2 * cols;
+    pw[c] = dw; pw[cols + c] = db;
 }
 // dw[c] += sum_g part[g][0][c], db[c] += sum_g part[g][1][c]   (fixed order)
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ part, int G, int cols, float* __restrict__ dw,
@@ -419,13 +427,17 @@ int vz_launch_rmsnorm_bwd(const bf16_t* x, const float* w, const bf16_t* dy, con
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
-// `part` holds G * 2 * cols floats, G = vz_layernorm_bwd_groups(rows)
-int vz_layernorm_bwd_groups(long rows) { return (int)(rows < 512 ? rows : 512); }
+// `part` holds G * 2 * cols floats (G = vz_layernorm_bwd_groups(rows)) followed by 2 * rows floats of row statistics
+int vz_layernorm_bwd_groups(long rows) { return (int)(rows < 128 ? rows : 128); }
+size_t vz_layernorm_bwd_scratch_floats(long rows, int cols) { return (size_t)vz_layernorm_bwd_groups(rows) * 2 * cols + 2 * (size_t)rows; }
 int vz_launch_layernorm_bwd(const bf16_t* x, const float* w, const bf16_t* dy, const bf16_t* dres, bf16_t* dx, float* part, float* dw, float* db,
                             long rows, int cols, float eps, hipStream_t s) {
-    VZ_CHECK_ARG(x && w && dy && part && dw && db && rows > 0 && cols > 0 && cols <= LN_MAX_PER_THREAD * 256, "layernorm_bwd: bad argument (cols <= %d)", LN_MAX_PER_THREAD * 256);
+    VZ_CHECK_ARG(x && w && dy && part && dw && db && rows > 0 && cols > 0 && (cols & 7) == 0, "layernorm_bwd: bad argument (cols %% 8)");
     const int G = vz_layernorm_bwd_groups(rows);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(G), dim3(256), 0, s, x, w, dy, dres, dx, part, rows, cols, eps);
+    float* stats = part + (size_t)G * 2 * cols;
+    hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, x, w, dy, dres, dx, stats, rows, cols, eps);
+    VZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_bwd_dwdb_kernel, dim3((cols + 255) / 256, G), dim3(256), 0, s, x, dy, stats, part, rows, cols);
     VZ_LAUNCH_CHECK();
     hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * cols + 255) / 256), dim3(256), 0, s, part, G, cols, dw, db);
     VZ_LAUNCH_CHECK();

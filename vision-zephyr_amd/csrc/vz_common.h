@@ -268,6 +268,7 @@ int vz_launch_softmax_bwd(const bf16_t* P, int ldp, const float* dP, int lddp, b
 int vz_launch_rmsnorm_bwd(const bf16_t* x, const float* w, const bf16_t* dy, const bf16_t* dres, bf16_t* dx, long rows, int cols, float eps,
                           hipStream_t s);
 int vz_layernorm_bwd_groups(long rows);
+size_t vz_layernorm_bwd_scratch_floats(long rows, int cols);
 int vz_launch_layernorm_bwd(const bf16_t* x, const float* w, const bf16_t* dy, const bf16_t* dres, bf16_t* dx, float* part, float* dw, float* db,
                             long rows, int cols, float eps, hipStream_t s);
 int vz_launch_gelu_fwd(const bf16_t* h, bf16_t* y, long n, hipStream_t s);
