@@ -325,7 +325,7 @@ int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_strea
  * 2 = prefill attention generation, 3 = split-K mode, 4 = 256^2 GEMM stream-K tail (1 = on, 0 = whole tiles only), 5 = stream-K skew in K-tiles, 6 = record 256^2 GEMM phase stamps,
  * 7 = route the collectives of a tp_size == 1 engine that holds a one-rank communicator through RCCL (self-test),
  * 9 = 2..16-row linears (1 = MFMA weight stream, 0 = GEMV / tile GEMM), 10 = context splits of the fused decode attention
- * (0 = engine default, 1..64), 13 = record role stamps of that launch, 15 = split-K factor of the K = 4096 projections on that route (default 8), 14 = rows from which a decode step's linears run on the 128^2 tile GEMM (default 25; 65 = never), 12 = one launch for QKV GEMV + attention + O GEMV of a batch-1 decode layer (1 = on; default 0), 11 = 256^2 GEMM workgroups wait for their epilogue stores before they end (experiment; 0 = off).
+ * (0 = engine default, 1..64), 13 = record role stamps of that launch, 16 = record stage stamps of the prefill attention kernel (vz_prof_attn_stamps), 15 = split-K factor of the K = 4096 projections on that route (default 8), 14 = rows from which a decode step's linears run on the 128^2 tile GEMM (default 25; 65 = never), 12 = one launch for QKV GEMV + attention + O GEMV of a batch-1 decode layer (1 = on; default 0), 11 = 256^2 GEMM workgroups wait for their epilogue stores before they end (experiment; 0 = off).
  * Process-wide. */
 int vz_tune_set(int knob, int value);
 
@@ -341,6 +341,9 @@ int vz_prof_gemm_stamps(long long* host_out, int max_wgs, int* n_wgs);
 /* same for the one-launch attention half of the batch-1 decode layer (vz_tune_set(13, 1)): 4 stamps per workgroup -
  * start | wait done | finished | left early - of the LAST stamped launch (tools/fused_stamps.py) */
 int vz_prof_attn_half_stamps(long long* host_out, int max_wgs, int* n_wgs);
+/* stage cycle counts (s_memtime) of one wave of the prefill attention kernel, last launch with vz_tune_set(16, 1): the longest
+ * causal workgroup's wave 0 - [issue K/V global loads, QK^T, softmax, PV, wait + LDS store, barrier, -, loop top, tiles]; 16 int64 */
+int vz_prof_attn_stamps(long long* host16);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,7 @@ struct FlashParams {
     float scale;
     int causal, q_pos0, window;
     const int* kv_len;
+    long long* stamps;      // profiling only (vz_tune_set(16, 1)): stage cycle counts of wave 0 of the longest causal workgroup
 };
 
 template <int HD, int KT>
@@ -260,7 +261,7 @@ __device__ __forceinline__ void softmax_tile(f32x4 (&sacc)[NT], float& m_run, fl
     }
 }
 
-template <int HD>
+template <int HD, bool STAMP>
 __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
     constexpr int KT = 64;
     constexpr int KS = HD * 2 + 16;          // K row stride in LDS (bytes)
@@ -289,6 +290,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
     const int q0 = qb * 128;
     const int hk = h / (p.Hq / p.Hkv);
     const int kv_len = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+    // stage stamps (shader cycles, s_memtime) of ONE wave: the last query block of head 0 (the longest causal workgroup)
+    const bool st_on = STAMP && p.stamps && qb == (int)gridDim.x - 1 && h == 0 && b == 0 && wave == 0;
+    long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define VZ_ST(i) if (STAMP && st_on) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t0; st_t0 = t_; }
+    if (STAMP && st_on) st_t0 = (long long)__builtin_amdgcn_s_memtime();
 
     bf16x8 qf0[DS], qf1[DS];
     int qrow0 = q0 + wave * 32 + c, qrow1 = qrow0 + 16;
@@ -363,7 +369,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
     int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
         const int key0 = t * KT;
+        VZ_ST(7)
         if (t + 1 < t_end) VZ_G_LOAD(t + 1)
+        VZ_ST(0)
         const char* Ks = smem + cur * BUF;
         const char* Vs = Ks + KT * KS;
         // The 64-key LDS tile is consumed as two 32-key halves: QK^T (2 key tiles) -> online softmax -> PV (one k-step).
@@ -388,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
                     sacc1[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ds], qf1[ds], sacc1[n2], 0, 0, 0);
                 }
             }
+            VZ_ST(1)
             bf16x8 pf0[1], pf1[1];
             // fully visible to this wave's 32 queries: below the causal diagonal of its first row, inside every row's
             // window, inside the valid keys (wave-uniform)
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
                 softmax_tile<2, DT, false>(sacc0, m_run0, l_run0, oacc0, pf0, hkey0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
                 softmax_tile<2, DT, false>(sacc1, m_run1, l_run1, oacc1, pf1, hkey0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
             }
+            VZ_ST(2)
             // ---- O^T += V^T P^T: each V^T fragment (two transposing reads) feeds both query tiles ----
 #pragma unroll
             for (int d4 = 0; d4 < DT; d4 += 4) {
@@ -417,10 +427,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
                 }
             }
         }
+        VZ_ST(3)
         if (t + 1 < t_end) VZ_L_STORE(cur ^ 1)
+        VZ_ST(4)
         __syncthreads();
+        VZ_ST(5)
         cur ^= 1;
     }
+    if (STAMP && st_on && lane == 0) {
+        for (int i = 0; i < 8; ++i) p.stamps[i] = st_acc[i];
+        p.stamps[8] = t_end - t_begin;
+    }
+#undef VZ_ST
 #undef VZ_G_LOAD
 #undef VZ_L_STORE
     if (q_valid0) {
@@ -452,7 +470,12 @@ int launch_flash2(const FlashParams& p, hipStream_t s) {
     constexpr int LDS = 2 * 64 * (HD * 2 + 16 + HD * 2 + 32);
     { int r = vz_init_attention_kernels(); if (r) return r; }
     dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
-    hipLaunchKernelGGL((flash_attn2_kernel<HD>), grid, dim3(256), LDS, s, p);
+    if (p.stamps) {
+        hipLaunchKernelGGL((flash_attn2_kernel<HD, true>), grid, dim3(256), LDS, s, p);
+        VZ_LAUNCH_CHECK();
+        return VZ_OK;
+    }
+    hipLaunchKernelGGL((flash_attn2_kernel<HD, false>), grid, dim3(256), LDS, s, p);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
@@ -577,6 +600,14 @@ static int set_flash_attr() {
     return VZ_OK;
 }
 
+static long long* g_attn_stamps = nullptr;
+int g_attn_stamp_on = 0;           // vz_tune_set(16, 1)
+int vz_attn_read_stamps(long long* host16) {
+    VZ_CHECK_ARG(host16 && g_attn_stamps, "attn stamps: not initialised");
+    VZ_CHECK_HIP(hipDeviceSynchronize());
+    VZ_CHECK_HIP(hipMemcpy(host16, g_attn_stamps, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    return VZ_OK;
+}
 static int g_attn_version = 2;     // 1 = v1 kernel for every head_dim (tests / A-B), 2 = v2 for head_dim 64 and 128
 void vz_set_attn_version(int v) { g_attn_version = v; }
 
@@ -584,8 +615,11 @@ int vz_init_attention_kernels() {
     static bool done = false;
     if (done) return VZ_OK;
     int r;
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 * 2 + 16 + 64 * 2 + 32)));
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 2 + 16 + 128 * 2 + 32)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 * 2 + 16 + 64 * 2 + 32)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 2 + 16 + 128 * 2 + 32)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 * 2 + 16 + 64 * 2 + 32)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 2 + 16 + 128 * 2 + 32)));
+    VZ_CHECK_HIP(hipMalloc((void**)&g_attn_stamps, 16 * sizeof(long long)));
     if ((r = set_flash_attr<64, 64>())) return r;
     if ((r = set_flash_attr<128, 64>())) return r;
     if ((r = set_flash_attr<512, 32>())) return r;
@@ -608,6 +642,7 @@ int vz_launch_attention(const AttnArgs& a, hipStream_t s) {
     p.q_bs = a.q_bs; p.q_ss = a.q_ss; p.q_hs = a.q_hs; p.k_bs = a.k_bs; p.k_ss = a.k_ss; p.k_hs = a.k_hs;
     p.v_bs = a.v_bs; p.v_ss = a.v_ss; p.v_hs = a.v_hs; p.o_bs = a.o_bs; p.o_ss = a.o_ss; p.o_hs = a.o_hs;
     p.scale = a.scale; p.causal = a.causal; p.q_pos0 = a.q_pos0; p.window = a.window; p.kv_len = a.kv_len;
+    p.stamps = g_attn_stamp_on ? g_attn_stamps : nullptr;
     if (g_attn_version != 1) {
         if (a.head_dim == 64) return launch_flash2<64>(p, s);
         if (a.head_dim == 128) return launch_flash2<128>(p, s);

@@ -1166,7 +1166,7 @@ extern "C" int vz_test_corrupt_streamk(vz_stream stream, int tile, int arrive, i
     return vz_gemm256_corrupt_tickets((hipStream_t)stream, tile, arrive, ready);
 }
 
-extern int g_gemm256_streamk, g_gemm256_skew, g_gemm256_stamps, g_gemm256_drain;
+extern int g_gemm256_streamk, g_gemm256_skew, g_gemm256_stamps, g_gemm256_drain, g_attn_stamp_on;
 int vz_gemm256_read_stamps(long long* host, int max_wgs, int* n_wgs);
 extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 0) { vz_set_gemv_variant(value); return VZ_OK; }
@@ -1182,6 +1182,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 12) { g_decode_fuse = value; return VZ_OK; }
     if (knob == 14) { g_decode_tile_rows = value; return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
+    if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }
     if (knob == 13) { g_decode_fuse_stamps = value; return VZ_OK; }
     if (knob == 10) { if (value < 0 || value > 64) { vz_set_error("tune_set: decode attention splits must be 0..64"); return VZ_ERR_ARG; } g_attn_nsplit = value; return VZ_OK; }
     vz_set_error("tune_set: unknown knob %d", knob);
@@ -1192,6 +1193,8 @@ int vz_attn_half_read_stamps(long long* host, int max_wgs, int* n_wgs, int* nB, 
 extern "C" int vz_prof_attn_half_stamps(long long* host_out, int max_wgs, int* n_wgs) {
     return vz_attn_half_read_stamps(host_out, max_wgs, n_wgs, nullptr, nullptr);
 }
+int vz_attn_read_stamps(long long* host16);
+extern "C" int vz_prof_attn_stamps(long long* host16) { return vz_attn_read_stamps(host16); }
 extern "C" int vz_prof_gemm_stamps(long long* host_out, int max_wgs, int* n_wgs) {
     return vz_gemm256_read_stamps(host_out, max_wgs, n_wgs);
 }

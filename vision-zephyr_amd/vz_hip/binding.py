@@ -79,6 +79,7 @@ SYMBOLS = {
     "vz_tp_all_gather": (_I, [_P, _P, _P, C.c_size_t, _P]),
     "vz_prof_enable": (_I, [_P, _I, _I]),
     "vz_prof_read": (_I, [_P, C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "vz_prof_attn_stamps": (_I, [C.POINTER(C.c_longlong)]),
     "vz_prof_gemm_stamps": (_I, [C.POINTER(C.c_longlong), _I, C.POINTER(_I)]),
     "vz_op_async_error": (_I, [_P, C.POINTER(_I)]),
     "vz_test_corrupt_streamk": (_I, [_P, _I, _I, _I]),
