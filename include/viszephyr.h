@@ -342,7 +342,8 @@ int vz_prof_gemm_stamps(long long* host_out, int max_wgs, int* n_wgs);
  * start | wait done | finished | left early - of the LAST stamped launch (tools/fused_stamps.py) */
 int vz_prof_attn_half_stamps(long long* host_out, int max_wgs, int* n_wgs);
 /* stage cycle counts (s_memtime) of one wave of the prefill attention kernel, last launch with vz_tune_set(16, 1): the longest
- * causal workgroup's wave 0 - [issue K/V global loads, QK^T, softmax, PV, wait + LDS store, barrier, -, loop top, tiles]; 16 int64 */
+ * causal workgroup's wave 0 - [issue K/V loads, QK^T, softmax, PV, wait, barrier, -, loop top, tiles] (16 int64), followed by 2048 x 4 int64
+ * of per-workgroup schedule: start, end (s_memrealtime, 100 MHz), XCC id << 32 | HW_ID, query block << 32 | tiles.  host buffer: 16 + 8192 int64 */
 int vz_prof_attn_stamps(long long* host16);
 
 #ifdef __cplusplus

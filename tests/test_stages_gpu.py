@@ -756,22 +756,31 @@ def test_continuous_batching_matches_static_batches(env):
         assert torch.equal(out[0], out[1])
         return out[0].tolist()
 
-    free_run = {i: static(i, None) for i in range(len(reqs))}
-    # an eos that request 1 emits at its 8th token (mid-chunk with sync_every = 4) and that hits nobody's first token
-    eos = free_run[1][7]
-    assume_ok = all(f[0] != eos for f in free_run.values())
-    got = dict(model.generate_stream(reqs, eos_token_id=[eos] if assume_ok else None, rows=3, sync_every=4))
-    assert sorted(got) == list(range(len(reqs)))
-    for i in range(len(reqs)):
-        want = free_run[i]
-        if assume_ok and eos in want:
-            want = want[: want.index(eos) + 1]
-        assert got[i].tolist() == want, f"request {i}: {got[i].tolist()} vs {want}"
-    # one row only degenerates to sequential generation and still agrees
-    got1 = dict(model.generate_stream(reqs[:3], eos_token_id=None, rows=1, sync_every=16))
-    for i in range(3):
-        g1, w = got1[i].tolist(), free_run[i]
-        assert g1[0] == w[0] and len(g1) == len(w)           # (a 1-row step runs the GEMV: a near-tie may flip later tokens)
+    # The multimodal request runs with 4 tiles in the static batch and 2 in the stream: under the production dispatch the 256^2
+    # GEMM's stream-K tail sums K in slices for the rows that fall into its split tiles, so a tile's visual tokens depend (in the last
+    # bf16 bit) on its position in the batch - ids would then agree only up to near-ties.  Whole tiles only (knob 4 = 0) is the
+    # batch-invariant kernel choice (as in test_full_size_request_properties): identical samples give identical rows, bit for bit.
+    from vz_hip import binding as B
+    try:
+        B.check(B.lib().vz_tune_set(4, 0))
+        free_run = {i: static(i, None) for i in range(len(reqs))}
+        # an eos that request 1 emits at its 8th token (mid-chunk with sync_every = 4) and that hits nobody's first token
+        eos = free_run[1][7]
+        assume_ok = all(f[0] != eos for f in free_run.values())
+        got = dict(model.generate_stream(reqs, eos_token_id=[eos] if assume_ok else None, rows=3, sync_every=4))
+        assert sorted(got) == list(range(len(reqs)))
+        for i in range(len(reqs)):
+            want = free_run[i]
+            if assume_ok and eos in want:
+                want = want[: want.index(eos) + 1]
+            assert got[i].tolist() == want, f"request {i}: {got[i].tolist()} vs {want}"
+        # one row only degenerates to sequential generation and still agrees
+        got1 = dict(model.generate_stream(reqs[:3], eos_token_id=None, rows=1, sync_every=16))
+        for i in range(3):
+            g1, w = got1[i].tolist(), free_run[i]
+            assert g1[0] == w[0] and len(g1) == len(w)           # (a 1-row step runs the GEMV: a near-tie may flip later tokens)
+    finally:
+        B.check(B.lib().vz_tune_set(4, 1))
     del model
     torch.cuda.empty_cache()
 

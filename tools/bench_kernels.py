@@ -226,12 +226,12 @@ def bench_attn():
     k = torch.randn(1, S, Hkv, D, device=dev).bfloat16()
     v = torch.randn(1, S, Hkv, D, device=dev).bfloat16()
     fl = 4.0 * S * S * D * Hq / 2
-    res = {1: [], 2: []}
+    res = {1: [], 2: [], 3: []}
     for rnd in range(3):
-        for ver in (1, 2):
+        for ver in (1, 2, 3):
             B.check(B.lib().vz_tune_set(2, ver))
             res[ver].append(timed(lambda i: B.attention(q, k, v, D ** -0.5, True, 0, 4096), 10))
-    B.check(B.lib().vz_tune_set(2, 2))
+    B.check(B.lib().vz_tune_set(2, 3))
     print(f"attn prefill causal S{S}: " + "  ".join(f"v{ver}: {min(t):7.1f} us {fl / min(t) / 1e6:6.1f} TF" for ver, t in res.items()), flush=True)
     kc = torch.randn(1, Hkv, S, D, device=dev).bfloat16()       # cache layout: keys of one head contiguous
     vc = torch.randn(1, Hkv, S, D, device=dev).bfloat16()
@@ -239,13 +239,13 @@ def bench_attn():
     print(f"attn prefill causal S{S} (KV-cache layout): v2 {us:7.1f} us {fl / us / 1e6:6.1f} TF", flush=True)
     T = 5
     qkv = torch.randn(T, 577, 3 * 1024, device=dev).bfloat16()
-    res = {1: [], 2: []}
+    res = {1: [], 2: [], 3: []}
     for rnd in range(3):
-        for ver in (1, 2):
+        for ver in (1, 2, 3):
             B.check(B.lib().vz_tune_set(2, ver))
             res[ver].append(timed(lambda i: B.attention(qkv[:, :, :1024].view(T, 577, 16, 64), qkv[:, :, 1024:2048].view(T, 577, 16, 64),
                                                         qkv[:, :, 2048:].view(T, 577, 16, 64), 0.125), 10))
-    B.check(B.lib().vz_tune_set(2, 2))
+    B.check(B.lib().vz_tune_set(2, 3))
     cf = 4.0 * 577 * 577 * 64 * 16 * T
     print(f"attn clip T{T}: " + "  ".join(f"v{ver}: {min(t):7.1f} us {cf / min(t) / 1e6:6.1f} TF" for ver, t in res.items()), flush=True)
     # decode attention at ctx 2048: fused vs two-kernel

@@ -261,11 +261,86 @@ __device__ __forceinline__ void softmax_tile(f32x4 (&sacc)[NT], float& m_run, fl
     }
 }
 
-template <int HD, bool STAMP>
+// Deferred-maximum form of the same step (guide section 5.5 T13; production since round 2): (a) the scores stay RAW in the accumulators and
+// the scale rides in the exponent's FMA - exp2(fma(s, scale * log2e, -m)); (b) the running maximum only advances when a tile's maximum
+// exceeds it by more than 8 (a factor 256 in P: harmless in the fp32 sums and in bf16's exponent), so the rescale of the 8 x 4 output
+// accumulators (16 packed multiplies + as many register copies per call in hipcc's code) and its exp2 leave almost every tile.  The
+// decision is per QUERY - the four lanes holding a query's statistics see the same all-reduced maximum - and every term of l and of
+// O^T added after a decision uses the same reference, so O / l is exact; probabilities are rounded to bf16 once, before PV, as before.
+template <int NT, int DT, bool FULL>
+__device__ __forceinline__ void softmax_tile_defer(f32x4 (&sacc)[NT], float& m_run, float& l_run, f32x4 (&oacc)[DT], bf16x8 (&pf)[NT / 2],
+                                                   int key0, int g, int kv_len, int causal, int qpos, int window, float scale_log2) {
+    // The kernel is bound by the ONE wave's instruction issue (the causal pairing leaves most SIMDs a single wave: ~675 instructions
+    // per 64-key tile at >= 4 cycles each against 64 MFMAs = 1024 matrix cycles), so the common path is kept to the minimum:
+    // * the tile maximum is taken per LANE (three-operand maxima) and only compared with the running one; the cross-lane all-reduce and
+    //   the rescale run when some query of the wave would grow by more than 8 - rare after the first tiles;
+    // * exponent arguments and row sums go through packed fp32 pairs (v_pk_fma_f32 / v_pk_add_f32);
+    // * l_run is a per-lane PARTIAL sum (the four lanes of a query hold disjoint keys); the kernel's epilogue adds them once.
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    float m_lane = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (!FULL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kidx = key0 + nt * 16 + 4 * g + r;
+                bool ok = kidx < kv_len;
+                if (causal) ok = ok && kidx <= qpos && (window <= 0 || kidx > qpos - window);
+                sacc[nt][r] = ok ? sacc[nt][r] : -INFINITY;
+            }
+        }
+        m_lane = fmaxf(fmaxf(m_lane, fmaxf(sacc[nt][0], sacc[nt][1])), fmaxf(sacc[nt][2], sacc[nt][3]));
+    }
+    if (__any(m_lane * scale_log2 > m_run + 8.0f)) {       // (m_run = -inf: any finite maximum grows it)
+        const float m_tile = rows_max(m_lane) * scale_log2;  // scale > 0: the maximum commutes with it; -inf stays -inf
+        const bool grow = m_tile > m_run + 8.0f;
+        const float m_new = grow ? m_tile : m_run;
+        const float alpha = grow ? __builtin_amdgcn_exp2f(m_run - (m_new == -INFINITY ? 0.f : m_new)) : 1.0f;
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha;
+        }
+        m_run = m_new;
+    }
+    const float m_safe = m_run == -INFINITY ? 0.f : m_run;
+    const f32x2 sc2 = {scale_log2, scale_log2}, nm2 = {-m_safe, -m_safe};
+    f32x2 ps = {0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const f32x2 a0 = (f32x2){sacc[nt][0], sacc[nt][1]} * sc2 + nm2, a1 = (f32x2){sacc[nt][2], sacc[nt][3]} * sc2 + nm2;
+        const f32x2 e0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+        const f32x2 e1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+        sacc[nt] = (f32x4){e0[0], e0[1], e1[0], e1[1]};
+        ps += e0 + e1;
+    }
+    l_run += ps[0] + ps[1];
+#pragma unroll
+    for (int s2 = 0; s2 < NT / 2; ++s2) {
+        bf16x8 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t[r] = (__bf16)sacc[2 * s2][r];
+            t[4 + r] = (__bf16)sacc[2 * s2 + 1][r];
+        }
+        pf[s2] = t;
+    }
+}
+
+template <int HD, bool STAMP, bool DEFER>
 __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
     constexpr int KT = 64;
-    constexpr int KS = HD * 2 + 16;          // K row stride in LDS (bytes)
-    constexpr int VS = HD * 2 + 32;          // V row stride: (VS/4) % 64 == 8 or 40 -> conflict-free tr-reads
+    // K arrives by LDS-DMA (global_load_lds, 16 bytes per lane, no staging registers, no ds_write): rows of HD * 2 bytes with NO
+    // padding - the DMA image is lane-linear, 1 KiB per wave-instruction - and an XOR swizzle of the 16-byte chunk index with the row,
+    // applied on the SOURCE address and again on the fragment read (16 lanes of a fragment read = 16 rows, same logical chunk ->
+    // 16 distinct physical chunks: conflict-free).  head_dim 128: 16 chunks per row, chunk ^= row & 15; head_dim 64: 8 chunks per
+    // row and two rows per 256-byte bank sweep, chunk ^= (row >> 1) & 7.
+    constexpr int KS = HD * 2;               // K row stride in LDS (bytes)
+    // V arrives the same way (round 2; it was staged through 16 VGPRs + ds_write_b128 before): rows of HD * 2 bytes, consumed by the
+    // transposing read ds_read_b64_tr_b16 - lane (g, c) takes 8 bytes of row 4g + (c >> 2) at column pair-of-chunks dt, bytes (c & 3) * 8.
+    // One pass of that read covers 8 rows x 32 bytes, so the swizzle works on 32-byte PAIRS of chunks: pair ^= row & 7 (head_dim 128,
+    // 8 pairs per row) or pair ^= (row >> 1) & 3 (head_dim 64: 4 pairs per row, two rows per 256-byte bank sweep).
+    constexpr int VS = HD * 2;
     constexpr int BUF = KT * (KS + VS);
     constexpr int NT = KT / 16, DS = HD / 32, DT = HD / 16, CPK = HD / 8;
     constexpr int NLD = (KT * CPK) / 256;    // 16-byte chunks per thread per operand tile
@@ -295,6 +370,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
     long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define VZ_ST(i) if (STAMP && st_on) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t0; st_t0 = t_; }
     if (STAMP && st_on) st_t0 = (long long)__builtin_amdgcn_s_memtime();
+    long long wg_t0 = 0;
+    if (STAMP && p.stamps && tid == 0) wg_t0 = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz, chip-wide: the schedule across CUs
 
     bf16x8 qf0[DS], qf1[DS];
     int qrow0 = q0 + wave * 32 + c, qrow1 = qrow0 + 16;
@@ -323,36 +400,36 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
         if (p.window > 0) k_begin = max(0, q0 + p.q_pos0 - p.window + 1);
     }
     const int t_begin = k_begin / KT, t_end = (k_end + KT - 1) / KT;
-    const bf16_t* kbase = p.k + (size_t)b * p.k_bs + (size_t)hk * p.k_hs;
-    const bf16_t* vbase = p.v + (size_t)b * p.v_bs + (size_t)hk * p.v_hs;
+    // wave-uniform bases, pinned into SGPRs (readfirstlane): the loads below then take the saddr + 32-bit voffset form, one VGPR per address
+    auto uniform_ptr = [](const bf16_t* ptr) {
+        const unsigned long long v = (unsigned long long)ptr;
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+        return (const char*)(((unsigned long long)hi << 32) | (unsigned long long)lo);       // (the builtin returns int: widen as UNSIGNED)
+    };
+    const char* kbase = uniform_ptr(p.k + (size_t)b * p.k_bs + (size_t)hk * p.k_hs);
+    const char* vbase = uniform_ptr(p.v + (size_t)b * p.v_bs + (size_t)hk * p.v_hs);
     const int last_key = kv_len > 0 ? kv_len - 1 : 0;
 
-    // split register staging (macros, not lambdas: arrays captured by reference end up in scratch)
-    typedef __attribute__((ext_vector_type(4))) unsigned stg_t;
-    stg_t kst[NLD], vst[NLD];
-#define VZ_G_LOAD(T)                                                                           \
+    // K: LDS-DMA; V: split register staging (macros, not lambdas: arrays captured by reference end up in scratch).  Source offsets
+    // are 32-bit (one batch's K/V of one head group stays below 4 GB) on the uniform bases: one v_mad per load instead of a 64-bit chain.
+    const unsigned k_ssb = (unsigned)p.k_ss * 2u, v_ssb = (unsigned)p.v_ss * 2u;
+#define VZ_G_LOAD(T, BUFI)                                                                     \
     {                                                                                          \
         const int key0_ = (T) * KT;                                                            \
+        char* Kd_ = smem + (BUFI) * BUF + wave * 1024;                                         \
         _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                      \
             const int ch = i * 256 + tid;                                                      \
-            const int kr = ch / CPK, dc = ch % CPK;                                            \
-            const int krow = min(key0_ + kr, last_key);                                        \
-            kst[i] = *(const stg_t*)(kbase + (size_t)krow * p.k_ss + dc * 8);                  \
-            vst[i] = *(const stg_t*)(vbase + (size_t)krow * p.v_ss + dc * 8);                  \
+            const int kr = ch / CPK, pc = ch % CPK;                                            \
+            const int lc = CPK == 16 ? (pc ^ (kr & 15)) : (pc ^ ((kr >> 1) & 7));              \
+            const int lv = CPK == 16 ? (pc ^ ((kr & 7) << 1)) : (pc ^ (((kr >> 1) & 3) << 1)); \
+            const unsigned krow = (unsigned)min(key0_ + kr, last_key);                         \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (krow * k_ssb + lc * 16)), \
+                                             (__attribute__((address_space(3))) void*)(Kd_ + i * 4096), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (krow * v_ssb + lv * 16)), \
+                                             (__attribute__((address_space(3))) void*)(Kd_ + KT * KS + i * 4096), 16, 0, 0); \
         }                                                                                      \
     }
-#define VZ_L_STORE(BUFI)                                                                       \
-    {                                                                                          \
-        char* Ks_ = smem + (BUFI) * BUF;                                                       \
-        char* Vs_ = Ks_ + KT * KS;                                                             \
-        _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                      \
-            const int ch = i * 256 + tid;                                                      \
-            const int kr = ch / CPK, dc = ch % CPK;                                            \
-            *(stg_t*)(Ks_ + kr * KS + dc * 16) = kst[i];                                       \
-            *(stg_t*)(Vs_ + kr * VS + dc * 16) = vst[i];                                       \
-        }                                                                                      \
-    }
-    if (t_begin < t_end) { VZ_G_LOAD(t_begin) VZ_L_STORE(0) }
+    if (t_begin < t_end) { VZ_G_LOAD(t_begin, 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     // The Q fragments came from global loads.  hipcc's waitcnt pass joins the loop's paths conservatively and would
     // otherwise wait for "the loads that may still be writing qf" right after each tile's prefetch is issued, i.e.
     // drain the prefetch every iteration.  Passing the fragments through an empty asm makes their producer opaque
@@ -364,71 +441,92 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
     }
     __syncthreads();
     // tr-read address of this lane inside a [16 keys][16 d] block: row q4 = (lane&15)>>2 of lane group g, columns 4p
-    const int tr_off = (4 * g + (c >> 2)) * VS + (c & 3) * 8;
+    const int tr_off = (4 * g + (c >> 2)) * VS + (c & 3) * 8;          // + ((pair ^ tr_sw) * 32): rows 16 apart share the swizzle term
+    const int tr_sw = CPK == 16 ? ((4 * g + (c >> 2)) & 7) : (((4 * g + (c >> 2)) >> 1) & 3);
     const float scale_log2 = p.scale * 1.4426950408889634f;
     int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
         const int key0 = t * KT;
         VZ_ST(7)
-        if (t + 1 < t_end) VZ_G_LOAD(t + 1)
+        if (t + 1 < t_end) VZ_G_LOAD(t + 1, cur ^ 1)
         VZ_ST(0)
         const char* Ks = smem + cur * BUF;
         const char* Vs = Ks + KT * KS;
-        // The 64-key LDS tile is consumed as two 32-key halves: QK^T (2 key tiles) -> online softmax -> PV (one k-step).
-        // Half the live score / probability registers of a 64-key step (no spills at head_dim 128), and the softmax VALU
-        // work of one half sits between MFMA groups of the other.
+        // The 64-key LDS tile is consumed as two 32-key halves, software-pipelined INSIDE the wave (the causal long / short pairing leaves
+        // most CUs with one wave per SIMD for most of the kernel, so nobody else fills the gaps): the QK^T MFMAs of BOTH halves are issued
+        // first, then the softmax of half 0 runs on the VALU while the matrix pipe works through half 1's QK^T, PV of half 0 is issued,
+        // and the softmax of half 1 runs under it (an MFMA holds the vector issue for 8 of its 16 cycles: MI355X_MICROARCH cycle constants).
+        // sched_barrier pins the order the source states.
         const int w_first = p.q_pos0 + q0 + wave * 32, w_last = w_first + 31;
+        f32x4 sacc0[4], sacc1[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            sacc0[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            sacc1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // two K fragments (8 VGPRs) in flight at a time: the kernel sits at the 256-register limit of two waves per SIMD, and a
+            // spilled loop invariant costs a scratch reload behind the in-flight K/V loads (vmcnt is in-order) every tile
+#pragma unroll
+            for (int d2 = 0; d2 < DS; d2 += 2) {
+                bf16x8 kf[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    kf[u] = *(const bf16x8*)(Ks + (nt * 16 + c) * KS + ((((d2 + u) * 4 + g) ^ (CPK == 16 ? c : (c >> 1))) << 4));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    sacc0[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u], qf0[d2 + u], sacc0[nt], 0, 0, 0);
+                    sacc1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u], qf1[d2 + u], sacc1[nt], 0, 0, 0);
+                }
+            }
+            if (nt == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        VZ_ST(1)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int hkey0 = key0 + hf * 32;
-            f32x4 sacc0[2], sacc1[2];
-#pragma unroll
-            for (int n2 = 0; n2 < 2; ++n2) {
-                const int nt = hf * 2 + n2;
-                bf16x8 kf[DS];   // all DS fragment reads of a key tile are issued before the first MFMA that needs one
-#pragma unroll
-                for (int ds = 0; ds < DS; ++ds) kf[ds] = *(const bf16x8*)(Ks + (nt * 16 + c) * KS + ds * 64 + g * 16);
-                sacc0[n2] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                sacc1[n2] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ds = 0; ds < DS; ++ds) {
-                    sacc0[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ds], qf0[ds], sacc0[n2], 0, 0, 0);
-                    sacc1[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ds], qf1[ds], sacc1[n2], 0, 0, 0);
-                }
-            }
-            VZ_ST(1)
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 (&sa0)[2] = *(f32x4(*)[2])&sacc0[2 * hf];
+            f32x4 (&sa1)[2] = *(f32x4(*)[2])&sacc1[2 * hf];
             bf16x8 pf0[1], pf1[1];
             // fully visible to this wave's 32 queries: below the causal diagonal of its first row, inside every row's
             // window, inside the valid keys (wave-uniform)
             const bool full = hkey0 + 32 <= kv_len && (!p.causal || (hkey0 + 31 <= w_first && (p.window <= 0 || hkey0 > w_last - p.window)));
-            if (full) {
-                softmax_tile<2, DT, true>(sacc0, m_run0, l_run0, oacc0, pf0, hkey0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
-                softmax_tile<2, DT, true>(sacc1, m_run1, l_run1, oacc1, pf1, hkey0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
+            if constexpr (DEFER) {
+                if (full) {
+                    softmax_tile_defer<2, DT, true>(sa0, m_run0, l_run0, oacc0, pf0, hkey0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
+                    softmax_tile_defer<2, DT, true>(sa1, m_run1, l_run1, oacc1, pf1, hkey0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
+                } else {
+                    softmax_tile_defer<2, DT, false>(sa0, m_run0, l_run0, oacc0, pf0, hkey0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
+                    softmax_tile_defer<2, DT, false>(sa1, m_run1, l_run1, oacc1, pf1, hkey0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
+                }
+            } else if (full) {
+                softmax_tile<2, DT, true>(sa0, m_run0, l_run0, oacc0, pf0, hkey0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
+                softmax_tile<2, DT, true>(sa1, m_run1, l_run1, oacc1, pf1, hkey0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
             } else {
-                softmax_tile<2, DT, false>(sacc0, m_run0, l_run0, oacc0, pf0, hkey0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
-                softmax_tile<2, DT, false>(sacc1, m_run1, l_run1, oacc1, pf1, hkey0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
+                softmax_tile<2, DT, false>(sa0, m_run0, l_run0, oacc0, pf0, hkey0, g, kv_len, p.causal, qpos0, p.window, scale_log2);
+                softmax_tile<2, DT, false>(sa1, m_run1, l_run1, oacc1, pf1, hkey0, g, kv_len, p.causal, qpos1, p.window, scale_log2);
             }
             VZ_ST(2)
+            __builtin_amdgcn_sched_barrier(0);
             // ---- O^T += V^T P^T: each V^T fragment (two transposing reads) feeds both query tiles ----
 #pragma unroll
-            for (int d4 = 0; d4 < DT; d4 += 4) {
-                bf16x8 vf[4];      // four V^T fragments (8 transposing reads) in flight before their MFMAs
+            for (int d4 = 0; d4 < DT; d4 += 2) {
+                bf16x8 vf[2];      // two V^T fragments (4 transposing reads) in flight before their MFMAs
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const char* vp = Vs + tr_off + (d4 + u) * 32;
+                for (int u = 0; u < 2; ++u) {
+                    const char* vp = Vs + tr_off + (((d4 + u) ^ tr_sw) << 5);
                     const bf16x4 v0 = lds_tr16(vp + (2 * hf) * 16 * VS);
                     const bf16x4 v1 = lds_tr16(vp + (2 * hf + 1) * 16 * VS);
                     vf[u] = (bf16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     oacc0[d4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], pf0[0], oacc0[d4 + u], 0, 0, 0);
                     oacc1[d4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], pf1[0], oacc1[d4 + u], 0, 0, 0);
                 }
             }
         }
         VZ_ST(3)
-        if (t + 1 < t_end) VZ_L_STORE(cur ^ 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the K / V DMA of tile t + 1 has landed (this wave's share; the barrier covers the others')
         VZ_ST(4)
         __syncthreads();
         VZ_ST(5)
@@ -438,9 +536,20 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
         for (int i = 0; i < 8; ++i) p.stamps[i] = st_acc[i];
         p.stamps[8] = t_end - t_begin;
     }
+    if (STAMP && p.stamps && tid == 0) {        // per workgroup: start, end (100 MHz), hardware id (XCC | SE | CU ...), tiles
+        const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (wg < 2048) {
+            long long* r = p.stamps + 16 + (size_t)wg * 4;
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            r[0] = wg_t0; r[1] = (long long)__builtin_amdgcn_s_memrealtime();
+            r[2] = ((long long)(xcc & 15) << 32) | hwid; r[3] = ((long long)qb << 32) | (t_end - t_begin);
+        }
+    }
 #undef VZ_ST
 #undef VZ_G_LOAD
-#undef VZ_L_STORE
+    if constexpr (DEFER) { l_run0 = rows_sum(l_run0); l_run1 = rows_sum(l_run1); }       // per-lane partial row sums -> the query's sum
     if (q_valid0) {
         const float inv = l_run0 > 0.f ? 1.0f / l_run0 : 0.f;
         bf16_t* op = p.o + (size_t)b * p.o_bs + (size_t)qrow0 * p.o_ss + (size_t)h * p.o_hs;
@@ -465,17 +574,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
     }
 }
 
+static int g_attn_version = 3;     // 1 = v1 kernel for every head_dim (tests / A-B), 2 = v2 (head_dim 64 / 128) with the classic online-softmax step, 3 = v2 with the deferred-maximum step (production)
 template <int HD>
 int launch_flash2(const FlashParams& p, hipStream_t s) {
-    constexpr int LDS = 2 * 64 * (HD * 2 + 16 + HD * 2 + 32);
+    constexpr int LDS = 2 * 64 * (HD * 2 + HD * 2);
     { int r = vz_init_attention_kernels(); if (r) return r; }
     dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
     if (p.stamps) {
-        hipLaunchKernelGGL((flash_attn2_kernel<HD, true>), grid, dim3(256), LDS, s, p);
+        hipLaunchKernelGGL((flash_attn2_kernel<HD, true, true>), grid, dim3(256), LDS, s, p);
         VZ_LAUNCH_CHECK();
         return VZ_OK;
     }
-    hipLaunchKernelGGL((flash_attn2_kernel<HD, false>), grid, dim3(256), LDS, s, p);
+    if (g_attn_version == 2) hipLaunchKernelGGL((flash_attn2_kernel<HD, false, false>), grid, dim3(256), LDS, s, p);
+    else hipLaunchKernelGGL((flash_attn2_kernel<HD, false, true>), grid, dim3(256), LDS, s, p);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
@@ -602,24 +713,26 @@ static int set_flash_attr() {
 
 static long long* g_attn_stamps = nullptr;
 int g_attn_stamp_on = 0;           // vz_tune_set(16, 1)
-int vz_attn_read_stamps(long long* host16) {
+int vz_attn_read_stamps(long long* host16) {          // 16 stage words + 2048 x 4 per-workgroup schedule words
     VZ_CHECK_ARG(host16 && g_attn_stamps, "attn stamps: not initialised");
     VZ_CHECK_HIP(hipDeviceSynchronize());
-    VZ_CHECK_HIP(hipMemcpy(host16, g_attn_stamps, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    VZ_CHECK_HIP(hipMemcpy(host16, g_attn_stamps, (16 + 2048 * 4) * sizeof(long long), hipMemcpyDeviceToHost));
     return VZ_OK;
 }
-static int g_attn_version = 2;     // 1 = v1 kernel for every head_dim (tests / A-B), 2 = v2 for head_dim 64 and 128
 void vz_set_attn_version(int v) { g_attn_version = v; }
 
 int vz_init_attention_kernels() {
     static bool done = false;
     if (done) return VZ_OK;
     int r;
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 * 2 + 16 + 64 * 2 + 32)));
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 2 + 16 + 128 * 2 + 32)));
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 * 2 + 16 + 64 * 2 + 32)));
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 2 + 16 + 128 * 2 + 32)));
-    VZ_CHECK_HIP(hipMalloc((void**)&g_attn_stamps, 16 * sizeof(long long)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<64, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 * 2 + 64 * 2)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<64, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 * 2 + 64 * 2)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<128, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 2 + 128 * 2)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<128, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 2 + 128 * 2)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<64, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 * 2 + 64 * 2)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 2 + 128 * 2)));
+    VZ_CHECK_HIP(hipMalloc((void**)&g_attn_stamps, (16 + 2048 * 4) * sizeof(long long)));
+    VZ_CHECK_HIP(hipMemset(g_attn_stamps, 0, (16 + 2048 * 4) * sizeof(long long)));
     if ((r = set_flash_attr<64, 64>())) return r;
     if ((r = set_flash_attr<128, 64>())) return r;
     if ((r = set_flash_attr<512, 32>())) return r;
