@@ -261,6 +261,12 @@ __device__ __forceinline__ void softmax_tile(f32x4 (&sacc)[NT], float& m_run, fl
     }
 }
 
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // Deferred-maximum form of the same step (guide section 5.5 T13; production since round 2): (a) the scores stay RAW in the accumulators and
 // the scale rides in the exponent's FMA - exp2(fma(s, scale * log2e, -m)); (b) the running maximum only advances when a tile's maximum
 // exceeds it by more than 8 (a factor 256 in P: harmless in the fp32 sums and in bf16's exponent), so the rescale of the 8 x 4 output
@@ -277,31 +283,41 @@ __device__ __forceinline__ void softmax_tile_defer(f32x4 (&sacc)[NT], float& m_r
     // * exponent arguments and row sums go through packed fp32 pairs (v_pk_fma_f32 / v_pk_add_f32);
     // * l_run is a per-lane PARTIAL sum (the four lanes of a query hold disjoint keys); the kernel's epilogue adds them once.
     typedef __attribute__((ext_vector_type(2))) float f32x2;
-    float m_lane = -INFINITY;
+    if (!FULL) {
+        // branch-free visibility: kidx in [lo, hi] (the short-circuit form compiled to a chain of exec-mask branches per element)
+        const int hi = causal ? min(kv_len - 1, qpos) : kv_len - 1;
+        const int lo = (causal && window > 0) ? qpos - window + 1 : 0;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        if (!FULL) {
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kidx = key0 + nt * 16 + 4 * g + r;
-                bool ok = kidx < kv_len;
-                if (causal) ok = ok && kidx <= qpos && (window <= 0 || kidx > qpos - window);
+                const bool ok = (kidx >= lo) & (kidx <= hi);
                 sacc[nt][r] = ok ? sacc[nt][r] : -INFINITY;
             }
-        }
-        m_lane = fmaxf(fmaxf(m_lane, fmaxf(sacc[nt][0], sacc[nt][1])), fmaxf(sacc[nt][2], sacc[nt][3]));
+    }
+    // per-lane maximum by three-operand maxima straight on the accumulators (fmaxf would first canonicalise every MFMA result)
+    float m_lane = vmax3(sacc[0][0], sacc[0][1], sacc[0][2]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (nt == 0) m_lane = vmax3(m_lane, sacc[0][3], sacc[NT - 1][3]);
+        else m_lane = vmax3(m_lane, sacc[nt][0], sacc[nt][1]);
+        if (nt > 0 && nt < NT - 1) m_lane = vmax3(m_lane, sacc[nt][2], sacc[nt][3]);
+        if (nt > 0 && nt == NT - 1) m_lane = vmax3(m_lane, sacc[nt][2], sacc[nt][2]);
     }
     if (__any(m_lane * scale_log2 > m_run + 8.0f)) {       // (m_run = -inf: any finite maximum grows it)
         const float m_tile = rows_max(m_lane) * scale_log2;  // scale > 0: the maximum commutes with it; -inf stays -inf
-        const bool grow = m_tile > m_run + 8.0f;
-        const float m_new = grow ? m_tile : m_run;
-        const float alpha = grow ? __builtin_amdgcn_exp2f(m_run - (m_new == -INFINITY ? 0.f : m_new)) : 1.0f;
-        l_run *= alpha;
+        // the rescale is a per-LANE conditional (the four lanes of a query agree): exec-masked in-place multiplies, so the common
+        // path carries the 64 accumulator registers through untouched (a wave-uniform select of alpha made hipcc copy them all)
+        if (m_tile > m_run + 8.0f) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_tile);      // m_tile is finite here; m_run = -inf gives 0
+            l_run *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha;
+            for (int dt = 0; dt < DT; ++dt) {
+                oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha;
+            }
+            m_run = m_tile;
         }
-        m_run = m_new;
     }
     const float m_safe = m_run == -INFINITY ? 0.f : m_run;
     const f32x2 sc2 = {scale_log2, scale_log2}, nm2 = {-m_safe, -m_safe};
