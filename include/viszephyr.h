@@ -35,7 +35,7 @@ extern "C" {
 #define VZ_ERR_UNSUPPORTED 4  /* reference-unreachable feature     -> NotImplementedError    */
 
 /* values of the async error word (vz_engine_async_error / vz_op_async_error): which bounded device-side wait expired */
-#define VZ_ASYNC_FUSED 1      /* hand-off of the one-launch attention half of a batch-1 decode layer (decode_fused.hip) */
+/* (1 was the hand-off of the one-launch batch-1 attention half, removed in round 2: it never beat the three kernels) */
 #define VZ_ASYNC_STREAMK 2    /* stream-K fix-up of the 256^2 GEMM: the tile was written as NaN, never as a sum of stale slots */
 
 typedef void* vz_stream;
@@ -338,9 +338,6 @@ int vz_prof_read(vz_engine* e, long* n_launches, double* total_ms);
 /* in-kernel phase stamps (s_memrealtime, 100 MHz) of the last 256^2 GEMM launched with vz_tune_set(6, 1):
  * 16 int64 per workgroup = {start, then per K-slice: loop begin, loop end, fix-up end, epilogue end, (nk<<32 | flags)} */
 int vz_prof_gemm_stamps(long long* host_out, int max_wgs, int* n_wgs);
-/* same for the one-launch attention half of the batch-1 decode layer (vz_tune_set(13, 1)): 4 stamps per workgroup -
- * start | wait done | finished | left early - of the LAST stamped launch (tools/fused_stamps.py) */
-int vz_prof_attn_half_stamps(long long* host_out, int max_wgs, int* n_wgs);
 /* stage cycle counts (s_memtime) of one wave of the prefill attention kernel, last launch with vz_tune_set(16, 1): the longest
  * causal workgroup's wave 0 - [issue K/V loads, QK^T, softmax, PV, wait, barrier, -, loop top, tiles] (16 int64), followed by 2048 x 4 int64
  * of per-workgroup schedule: start, end (s_memrealtime, 100 MHz), XCC id << 32 | HW_ID, query block << 32 | tiles.  host buffer: 16 + 8192 int64 */

@@ -304,44 +304,6 @@ def test_decode_graph_equals_eager(env):
     assert eager.tolist() == graph.tolist()
 
 
-@pytest.mark.parametrize("ctx", [24, 200, 300])
-def test_one_launch_attention_half_equals_three_kernels(env, ctx):
-    """Batch-1 decode runs QKV GEMV + attention + O GEMV of a layer as roles of ONE launch that hand over through device-side
-    counters (decode_fused.hip).  Same arithmetic in the same order: the logits of every step and the ids must be BIT-IDENTICAL to
-    the three-kernel path (vz_tune_set(12, 0)), eagerly and under graph replay, across the context-split buckets (ctx 24: one
-    split; 200: two; 300: three, of which the last holds the new token), and no device-side wait may have expired."""
-    from vz_hip import binding as B
-    cfg, model = env["cfg"], env["model"]
-    eng = model.engine
-    ids = env["synth"].synth_ids(ctx, cfg.vocab, image_pos=-1, seed=31)
-    emb = eng.embed_tokens(ids).unsqueeze(0)
-
-    def run(n, logits):
-        _, last = eng.prefill(emb, [ctx])
-        eng.decode_begin(last.argmax(-1).to(torch.int32), [ctx], [ctx])
-        out = eng.decode_steps(n, return_logits=logits)
-        torch.cuda.synchronize()
-        return out
-
-    B.check(B.lib().vz_tune_set(12, 0))
-    ref_ids, ref_lg = run(6, True)
-    ref_graph = run(12, False).clone()
-    try:
-        B.check(B.lib().vz_tune_set(12, 1))          # opt-in (default off: not faster than the three kernels yet)
-        ids1, lg1 = run(6, True)
-        eng.check_async()
-        assert torch.equal(lg1, ref_lg), f"max logit diff {float((lg1 - ref_lg).abs().max()):.3e}"
-        assert torch.equal(ids1, ref_ids)
-        for rep in range(3):
-            got = run(12, False)
-            eng.check_async()
-            assert torch.equal(got, ref_graph), f"graph replay {rep}"
-            assert eng.decode_mode()[0]
-            torch.randn(1 << 22, device="cuda").sum()
-    finally:
-        B.check(B.lib().vz_tune_set(12, 0))
-
-
 def test_batched_generate_and_left_padding(env):
     """true batching (one weight stream for all rows) must give every row exactly what it gets alone, and a left-padded
     batch (tokenizer_padding_side='left') must score like the same batch right-padded."""

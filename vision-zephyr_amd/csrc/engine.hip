@@ -176,7 +176,6 @@ struct vz_engine {
     // decode state (device)
     int* d_state = nullptr;  // [cur_ids[B] | pos[B] | slot[B] | len[B] | step]
     int dec_B = 0;
-    bool fuse_ok = true;         // the one-launch attention half fits the device (resident slots for its waiting workgroups)
     bool comm_graph_ok = true;   // RCCL collectives captured into the decode graph (cleared if a capture is refused -> eager steps)
     int dec_len_max = 0;         // host-side bound on the longest row's visible keys (grows by one per launched step)
     // host mirror of the device-side decode state, per row: keys visible to the NEXT step, its rotary position, and whether the
@@ -191,11 +190,10 @@ struct vz_engine {
     bf16_t* d_xnorm = nullptr;   // [64, hidden]: normalised rows of a 5..16-row decode batch (the MFMA weight stream reads them from L2)
     float* d_part = nullptr;     // decode attention partials
     unsigned* d_ticket = nullptr; // arrival counters of the fused decode attention
-    unsigned* d_fcount = nullptr; // [n_layers][1024] hand-off flags of the one-launch attention half (decode_fused.hip)
     int* d_ferr = nullptr;        // raised by a bounded device-side wait that expired
     int nsplit = 32;                 // upper bound: a split takes >= 128 keys, the splits beyond ceil(len / 128) leave at once
     hipStream_t cap_stream = nullptr;   // stream capture is not allowed on the legacy null stream torch hands us
-    hipGraphExec_t dec_graph = nullptr; int dec_graph_B = 0, dec_graph_n = 0, dec_graph_nsplit = 0, dec_graph_fuse = -1; long dec_graph_samp[6] = {0, 0, 0, 0, 0, 0}; int* dec_graph_out = nullptr; char* dec_graph_arena = nullptr;
+    hipGraphExec_t dec_graph = nullptr; int dec_graph_B = 0, dec_graph_n = 0, dec_graph_nsplit = 0; long dec_graph_samp[6] = {0, 0, 0, 0, 0, 0}; int* dec_graph_out = nullptr; char* dec_graph_arena = nullptr;
     int* h_pinned = nullptr;     // pinned staging for small host->device uploads
     size_t h_pinned_ints = 0;
     // profiling
@@ -232,7 +230,7 @@ struct ProfScope {
             }
             idx = e->prof_used++;
             on = true;
-            if (klass == K_GEMM || klass == K_GEMV || klass == K_FUSED) {      // stamped by the launch itself (kernel-only duration)
+            if (klass == K_GEMM || klass == K_GEMV) {      // stamped by the launch itself (kernel-only duration)
                 g_vz_prof_start = e->prof_ev[idx].first;
                 g_vz_prof_stop = e->prof_ev[idx].second;
                 ext = true;
@@ -360,8 +358,6 @@ extern "C" int vz_engine_create(const vz_config* cfg, vz_engine** out) {
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_ticket, 4096);
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_xnorm, (size_t)64 * c.hidden * sizeof(bf16_t));
     if (er == hipSuccess) er = hipMemset(e->d_ticket, 0, 4096);
-    if (er == hipSuccess) er = hipMalloc((void**)&e->d_fcount, (size_t)c.n_layers * 1024 * sizeof(unsigned));
-    if (er == hipSuccess) er = hipMemset(e->d_fcount, 0, (size_t)c.n_layers * 1024 * sizeof(unsigned));
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_ferr, sizeof(int));
     if (er == hipSuccess) er = hipMemset(e->d_ferr, 0, sizeof(int));
     if (er != hipSuccess) {
@@ -385,7 +381,6 @@ extern "C" int vz_engine_destroy(vz_engine* e) {
     if (e->d_logits) hipFree(e->d_logits);
     if (e->d_part) hipFree(e->d_part);
     if (e->d_ticket) hipFree(e->d_ticket);
-    if (e->d_fcount) hipFree(e->d_fcount);
     if (e->d_ferr) hipFree(e->d_ferr);
     if (e->d_xnorm) hipFree(e->d_xnorm);
     if (e->d_gather) (void)hipFree(e->d_gather);
@@ -945,29 +940,6 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
     { ProfScope ps(e, K_OTHER, s); RC(vz_launch_embed_tokens(cur, B, H, WB("llm.embed", (long)c.vocab * H), x, s)); }
     for (int i = 0; i < c.n_layers; ++i) {
         const std::string p = "llm." + std::to_string(i) + ".";
-        bool fused = false;
-        if (B == 1 && tp_local(e)) {
-            // batch-1: QKV GEMV + attention + O GEMV as roles of ONE launch (decode_fused.hip)
-            AttnHalfArgs f;
-            f.x = x; f.norm_w = WF(p + "in_norm", H); f.norm_eps = c.rms_eps;
-            f.Wqkv = WB(p + "qkv.w", (long)QKV * H); f.Wqkv8 = W8(p + "qkv.w8", (long)QKV * H); f.sqkv = WS(p + "qkv.ws", QKV);
-            f.Wo = WB(p + "o.w", (long)H * A); f.Wo8 = W8(p + "o.w8", (long)H * A); f.so = WS(p + "o.ws", H);
-            f.fp8 = f.Wqkv8 && f.sqkv && f.Wo8 && f.so;
-            f.qkv = qkv; f.att = att; f.kc = kc_of(e, i); f.vc = vc_of(e, i); f.part = e->d_part; f.split_ticket = e->d_ticket;
-            f.cosT = e->cosT; f.sinT = e->sinT; f.pos = pos; f.slot = slot;
-            f.H = H; f.QKV = QKV; f.A = A; f.Hq = Hq; f.Hkv = Hkv; f.max_ctx = c.max_ctx; f.nsplit = e->dec_nsplit; f.window = c.sliding_window;
-            f.scale = 0.08838834764831845f;
-            f.tq = e->d_fcount + (size_t)i * 1024; f.to = f.tq + 960; f.step = step; f.err = e->d_ferr;
-            if (rc) return rc;
-            if (Hkv <= 8 && D == 128 && e->fuse_ok && vz_attn_half_ok(f)) {
-                if (g_decode_fuse == 2)         // attention + O only: the QKV GEMV stays its own launch
-                    RC(linear(e, 1, x, H, f.Wqkv, H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, f.norm_w, c.rms_eps, f.Wqkv8, f.sqkv));
-                ProfScope ps(e, K_FUSED, s);
-                RC(vz_launch_attn_half(f, s));
-                fused = true;
-            }
-        }
-        if (!fused) {
         RC(linear(e, 1, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps,
                   W8(p + "qkv.w8", (long)QKV * H), WS(p + "qkv.ws", QKV)));
         {
@@ -981,7 +953,6 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
         }
         RC(linear(e, 1, att, A, WB(p + "o.w", (long)H * A), A, x, H, B, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
                   W8(p + "o.w8", (long)H * A), WS(p + "o.ws", H)));
-        }
         RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
         RC(linear(e, 1, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps,
                   W8(p + "gu.w8", 2L * I * H), WS(p + "gu.ws", 2L * I)));
@@ -1055,10 +1026,6 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     const int B = e->dec_B;
     const size_t need = ((size_t)B * (3 * c.hidden + (c.n_heads + 2 * c.n_kv_heads) * c.head_dim + c.inter)) * 2 + 8192;   // upper bound (tp = 1 sizes)
     RC(ensure_arena(e, need));
-    if (B == 1 && tp_local(e) && g_decode_fuse) {      // occupancy of the one-launch attention half (queried outside any capture)
-        const int cap = vz_attn_half_capacity(c.weight_fp8 != 0);
-        e->fuse_ok = cap > 0 && e->nsplit * e->Hkv_l + 64 <= cap;
-    }
     // tensor-parallel steps: the RCCL all-reduces / all-gather are captured with the kernels (one graph launch per token instead of
     // ~230 host launches); if RCCL refuses the capture the engine falls back to eager steps for good
     bool use_graph = !e->prof_on && !d_logits_dbg && getenv("VZ_NO_GRAPH") == nullptr &&
@@ -1066,7 +1033,6 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     if (!tp_local(e)) RC(ensure_gather(e, B, s));
     int* step = e->d_state + 4 * c.max_batch;
     VZ_CHECK_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
-    VZ_CHECK_HIP(hipMemsetAsync(e->d_fcount, 0, (size_t)c.n_layers * 1024 * sizeof(unsigned), s));   // hand-off counters count from step 0
     // Capacity (the cache append writes slot = len - 1 of the row, the rotary tables are read at pos): every live row must still fit
     // after n steps.  Parked rows (continuous batching) are not checked: the step tail saturates their slot / position on the device.
     int len_max = 0;
@@ -1104,7 +1070,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     long samp_key[6] = {e->samp_on, e->samp_top_k, 0, 0, (long)(uintptr_t)e->ring, e->ring_n};
     memcpy(&samp_key[2], &e->samp_temp, 4); memcpy(&samp_key[3], &e->samp_top_p, 4);
     if (!e->dec_graph || e->dec_graph_B != B || e->dec_graph_n != n || e->dec_graph_out != d_out_ids || e->dec_graph_arena != e->arena ||
-        e->dec_graph_nsplit != e->dec_nsplit || e->dec_graph_fuse != g_decode_fuse || memcmp(e->dec_graph_samp, samp_key, sizeof(samp_key)) != 0) {
+        e->dec_graph_nsplit != e->dec_nsplit || memcmp(e->dec_graph_samp, samp_key, sizeof(samp_key)) != 0) {
         if (e->dec_graph) { hipGraphExecDestroy(e->dec_graph); e->dec_graph = nullptr; }
         hipGraph_t graph;
         if (!e->cap_stream) VZ_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
@@ -1122,7 +1088,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
             for (int i = 0; i < n; ++i) RC(decode_step_launch(e, d_out_ids, n, nullptr, s));
             return VZ_OK;
         }
-        e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena; e->dec_graph_nsplit = e->dec_nsplit; e->dec_graph_fuse = g_decode_fuse; memcpy(e->dec_graph_samp, samp_key, sizeof(samp_key));
+        e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena; e->dec_graph_nsplit = e->dec_nsplit; memcpy(e->dec_graph_samp, samp_key, sizeof(samp_key));
     }
     for (int i = 0; i < n; ++i) VZ_CHECK_HIP(hipGraphLaunch(e->dec_graph, s));
     return VZ_OK;
@@ -1146,8 +1112,7 @@ extern "C" int vz_engine_async_error(vz_engine* e, int* err) {
     VZ_CHECK_HIP(hipMemcpy(err, e->d_ferr, sizeof(int), hipMemcpyDeviceToHost));
     if (*err) {
         VZ_CHECK_HIP(hipMemset(e->d_ferr, 0, sizeof(int)));
-        // the hand-off words / tickets that made a wait expire are in an unknown state: start the next launch from zero
-        VZ_CHECK_HIP(hipMemset(e->d_fcount, 0, (size_t)e->c.n_layers * 1024 * sizeof(unsigned)));
+        // the stream-K tickets that made a wait expire are in an unknown state: start the next launch from zero
         int dummy = 0;
         RC(vz_gemm256_async_error(e->last_stream, &dummy, true));
     }
@@ -1179,20 +1144,14 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 7) { g_force_comm = value; return VZ_OK; }
     if (knob == 9) { g_skinny_mode = value; return VZ_OK; }
     if (knob == 11) { g_gemm256_drain = value; return VZ_OK; }
-    if (knob == 12) { g_decode_fuse = value; return VZ_OK; }
     if (knob == 14) { g_decode_tile_rows = value; return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }
-    if (knob == 13) { g_decode_fuse_stamps = value; return VZ_OK; }
     if (knob == 10) { if (value < 0 || value > 64) { vz_set_error("tune_set: decode attention splits must be 0..64"); return VZ_ERR_ARG; } g_attn_nsplit = value; return VZ_OK; }
     vz_set_error("tune_set: unknown knob %d", knob);
     return VZ_ERR_ARG;
 }
 
-int vz_attn_half_read_stamps(long long* host, int max_wgs, int* n_wgs, int* nB, int* nA);
-extern "C" int vz_prof_attn_half_stamps(long long* host_out, int max_wgs, int* n_wgs) {
-    return vz_attn_half_read_stamps(host_out, max_wgs, n_wgs, nullptr, nullptr);
-}
 int vz_attn_read_stamps(long long* host16);
 extern "C" int vz_prof_attn_stamps(long long* host16) { return vz_attn_read_stamps(host16); }
 extern "C" int vz_prof_gemm_stamps(long long* host_out, int max_wgs, int* n_wgs) {

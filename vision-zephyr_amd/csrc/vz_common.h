@@ -215,25 +215,6 @@ struct AttnDecodeFusedArgs {
 };
 int vz_launch_attn_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s);
 
-// decode_fused.hip: QKV GEMV (+RMSNorm) + fused decode attention + O GEMV (+residual) of ONE batch-1 layer in one launch
-struct AttnHalfArgs {
-    bf16_t* x; const float* norm_w; float norm_eps;
-    const bf16_t* Wqkv; const unsigned char* Wqkv8; const float* sqkv;
-    const bf16_t* Wo; const unsigned char* Wo8; const float* so;
-    bf16_t *qkv, *att;                 // scratch rows [QKV], [A]
-    bf16_t *kc, *vc; float* part; unsigned* split_ticket;
-    const float *cosT, *sinT; const int *pos, *slot;
-    int H, QKV, A, Hq, Hkv, max_ctx, nsplit, window;
-    float scale;
-    unsigned *tq, *to;                 // hand-off flags of this layer: [QKV / 8] (<= 960), [Hkv]; zero when `*step` is zero
-    const int* step;                   // device-side token counter (vz_llm_decode_steps)
-    int* err;                          // device word raised when a bounded wait expires
-    bool fp8;
-};
-bool vz_attn_half_ok(const AttnHalfArgs& a);
-int vz_launch_attn_half(const AttnHalfArgs& a, hipStream_t s);
-int vz_attn_half_capacity(bool fp8);
-extern int g_decode_fuse, g_decode_fuse_stamps;
 
 int vz_launch_rope_kv(const bf16_t* qkv, int ld, bf16_t* q_out, bf16_t* kc, bf16_t* vc, const float* cosT,
                       const float* sinT, const int* pos, const int* slot, int B, int S, int Hq, int Hkv, int D,

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libviszephyr_hip.so")
 
 VZ_OK, VZ_ERR_ARG, VZ_ERR_HIP, VZ_ERR_STATE, VZ_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
-VZ_ASYNC_FUSED, VZ_ASYNC_STREAMK = 1, 2
+VZ_ASYNC_STREAMK = 2
 ABI_VERSION = 5
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
 K_GEMM, K_GEMV, K_ATTN, K_ATTN_DEC, K_NORM, K_OTHER, K_FUSED, K_COMM = range(8)
@@ -69,7 +69,6 @@ SYMBOLS = {
     "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
     "vz_llm_decode_mode": (_I, [_P, _P, _P]),
     "vz_engine_async_error": (_I, [_P, _P]),
-    "vz_prof_attn_half_stamps": (_I, [_P, _I, _P]),
     "vz_tune_set": (_I, [_I, _I]),
     "vz_engine_resize_vocab": (_I, [_P, _I]),
     "vz_op_resample_u8": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P]),

@@ -470,13 +470,12 @@ class Engine:
         B.check(self.lib.vz_llm_decode_ring(self.h, B.ptr(ring), 0 if ring is None else ring.numel()))
 
     def check_async(self):
-        """raise if a bounded device-side wait expired since the last check (outputs invalid): the hand-off of the one-launch
-        attention half of a batch-1 decode layer, or the stream-K fix-up of the 256^2 GEMM (its tile is NaN, never a stale sum)."""
+        """raise if a bounded device-side wait expired since the last check (outputs invalid): the stream-K fix-up of
+        the 256^2 GEMM (its tile is NaN, never a stale sum)."""
         err = C.c_int(0)
         B.check(self.lib.vz_engine_async_error(self.h, C.byref(err)))
         if err.value:
-            what = {B.VZ_ASYNC_FUSED: "hand-off of the fused decode launch (vz_tune_set(12, 0) turns it off)",
-                    B.VZ_ASYNC_STREAMK: "stream-K fix-up of the 256^2 GEMM (another launch shared its tickets?)"}.get(err.value, f"code {err.value}")
+            what = {B.VZ_ASYNC_STREAMK: "stream-K fix-up of the 256^2 GEMM (another launch shared its tickets?)"}.get(err.value, f"code {err.value}")
             raise RuntimeError(f"vz_hip: a bounded device-side wait expired ({what}); outputs since the last check are invalid")
 
     def decode_mode(self):
