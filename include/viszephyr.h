@@ -77,6 +77,14 @@ int vz_op_linear_fp8(const void* d_A, int lda, const void* d_W8, int ldw, const 
  * lm_head; hf:models/mistral/modeling_mistral.py:182-199), then vz_op_linear's contract without bias.  1 <= M <= 16. */
 int vz_op_linear_rmsnorm(const void* d_A, int lda, const float* d_norm_w, float norm_eps, const void* d_W, int ldw, void* d_C, int ldc,
                          int M, int N, int K, const void* d_residual, int ldr, int act, int out_fp32, vz_stream stream);
+/* Fragment-tiled copy of a dense bf16 weight [N, K] (N % 16 == 0, K % 64 == 0) for the 2..64-row MFMA weight stream: the 16 bytes
+ * W[16 G + r][64 s + 16 g + 8 j .. + 7] move to chunk ((G * K/64 + s) * 2 + j) * 64 + (16 g + r), so that every wave-instruction of the
+ * stream reads 1 KiB contiguous.  An engine uses the copy registered as "<weight name>t" (same element count) for its decode
+ * linears; vz_op_linear_tiled is the same launch at op level (results bit-identical to the row-major stream, impl 3). */
+int vz_op_tile_weights(const void* d_W, int N, int K, int ldw, void* d_Wt, vz_stream stream);
+int vz_op_linear_tiled(const void* d_A, int lda, const void* d_W, const void* d_Wt, int ldw, void* d_C, int ldc, int M, int N, int K,
+                       const float* d_bias, const void* d_residual, int ldr, int act, int out_fp32, const float* d_norm_w,
+                       float norm_eps, vz_stream stream);
 /* same contract, forcing one implementation (tests): impl 0 = 128^2 MFMA tile GEMM, 1 = GEMV (M <= 8), 2 = 256^2 tile GEMM,
  * 3 = MFMA weight stream for 2 <= M <= 64 (batched decode), 4 = the 128^2 tile GEMM with the finer split-K of the 17..64-row decode route */
 int vz_op_linear_impl(int impl, const void* d_A, int lda, const void* d_W, int ldw, void* d_C, int ldc,

@@ -764,3 +764,26 @@ def test_decode_tile_route_splitk(B, M, N, K, act):
     o16 = B.linear(x, w, residual=res, act=act, impl=4)
     check_close("bf16 out", o16, _ref_linear(x, w, None, res, act), BF16_MAX, BF16_L2)
     assert torch.equal(B.linear(x, w, residual=res, act=act, out_fp32=True, impl=4), out)
+
+
+@pytest.mark.parametrize("M,N,K,act,norm", [(2, 6144, 4096, 0, True), (3, 4096, 4096, 0, False), (7, 28672, 4096, 3, True), (16, 4096, 14336, 0, False),
+                                            (16, 28672, 4096, 3, True), (24, 6144, 4096, 0, False), (40, 28672, 4096, 3, False), (64, 4096, 14336, 0, False)])
+def test_skinny_tiled_weights_bit_identical(B, M, N, K, act, norm):
+    """the fragment-tiled copy of a weight (vz_op_tile_weights) holds the same values in the order the MFMA weight stream consumes them:
+    the layout equals its definition (include/viszephyr.h), and a launch on it equals the row-major launch bit for bit - fused RMSNorm,
+    SwiGLU pairs, residual, 2..64 rows (two and four B operands per fragment)."""
+    x = _rand((M, K), 1.0, 90).bfloat16()
+    w = (_rand((N, K), 1.0, 91) * K ** -0.5).bfloat16()
+    wt = B.tile_weights(w)
+    ref_t = w.view(N // 16, 16, K // 64, 4, 2, 8).permute(0, 2, 4, 3, 1, 5).contiguous().view(-1)      # (G, r, s, g, j, e) -> (G, s, j, g, r, e)
+    assert torch.equal(wt, ref_t)
+    n_out = N // 2 if act == 3 else N
+    res = _rand((M, n_out), 1.0, 92).bfloat16()
+    nw = (_rand((K,), 0.2, 93) + 1.0) if norm and M <= 16 else None
+    if nw is not None:
+        a = B.linear_rmsnorm(x, nw, 1e-5, w, residual=res, act=act)
+        b = B.linear_tiled(x, w, wt, residual=res, act=act, norm_w=nw, norm_eps=1e-5)
+    else:
+        a = B.linear(x, w, residual=res, act=act, impl=3)
+        b = B.linear_tiled(x, w, wt, residual=res, act=act)
+    assert torch.equal(a, b), f"max diff {float((a.float() - b.float()).abs().max()):.3e}"

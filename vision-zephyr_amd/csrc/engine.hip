@@ -89,6 +89,18 @@ extern "C" int vz_op_linear_rmsnorm(const void* A, int lda, const float* norm_w,
     VZ_CHECK_ARG((g_skinny_mode && vz_skinny_ok(a)) || vz_gemv_ok(a), "linear_rmsnorm: shape M=%d K=%d not supported by the weight-stream kernels", M, K);
     return vz_launch_linear(a, (hipStream_t)s);
 }
+extern "C" int vz_op_tile_weights(const void* W, int N, int K, int ldw, void* Wt, vz_stream s) {
+    return vz_launch_tile_weights((const bf16_t*)W, N, K, ldw, (bf16_t*)Wt, (hipStream_t)s);
+}
+extern "C" int vz_op_linear_tiled(const void* A, int lda, const void* W, const void* Wt, int ldw, void* C, int ldc, int M, int N, int K,
+                                  const float* bias, const void* residual, int ldr, int act, int out_fp32, const float* norm_w,
+                                  float norm_eps, vz_stream s) {
+    VZ_CHECK_ARG(Wt && ldw == K && (N & 15) == 0, "linear_tiled: needs the tiled copy of a dense [N, K] weight with N %% 16 == 0");
+    LinearArgs a = mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, act, out_fp32);
+    a.Wt = (const bf16_t*)Wt; a.norm_w = norm_w; a.norm_eps = norm_eps;
+    VZ_CHECK_ARG(g_skinny_mode && vz_skinny_ok(a), "linear_tiled: the MFMA weight stream takes 2 <= M <= 64 (fused norm: <= 16), K %% 64 == 0 (M=%d K=%d)", M, K);
+    return vz_launch_skinny(a, (hipStream_t)s);
+}
 extern "C" int vz_op_linear_impl(int impl, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N,
                                  int K, const float* bias, const void* residual, int ldr, int act, int out_fp32,
                                  vz_stream s) {
@@ -166,6 +178,9 @@ struct vz_engine {
     float* d_gather = nullptr;     // [tp][rows][Vp] all-gathered logits before the repack
     size_t gather_floats = 0;
     std::unordered_map<std::string, Weight> w;
+    // row-major bf16 weight -> its fragment-tiled copy (registered as "<name>t", same element count): the 2..64-row decode
+    // linears stream the tiled copy (gemm_skinny.hip); rebuilt whenever the registry changes
+    std::unordered_map<const void*, const bf16_t*> tiled; bool tiled_dirty = true;
     bool finalized = false;
     // rope
     const float* cosT = nullptr; const float* sinT = nullptr; int rope_max = 0;
@@ -254,6 +269,19 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
                   const float* norm_w = nullptr, float norm_eps = 0.f, const unsigned char* W8 = nullptr, const float* ws = nullptr) {
     LinearArgs a = mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, res, ldr, act, out_fp32);
     a.norm_w = norm_w; a.norm_eps = norm_eps; a.err = e->d_ferr; e->last_stream = s;
+    if (klass_hint == 1 && M >= 2 && ldw == K) {       // decode step: the fragment-tiled copy of this weight, if the caller registered one
+        if (e->tiled_dirty) {
+            e->tiled.clear();
+            for (const auto& kv : e->w) {
+                if (kv.second.dtype != 0 || kv.first.empty() || kv.first.back() != 't') continue;
+                auto base = e->w.find(kv.first.substr(0, kv.first.size() - 1));
+                if (base != e->w.end() && base->second.dtype == 0 && base->second.n == kv.second.n) e->tiled[base->second.p] = (const bf16_t*)kv.second.p;
+            }
+            e->tiled_dirty = false;
+        }
+        auto it = e->tiled.find((const void*)W);
+        if (it != e->tiled.end()) a.Wt = it->second;
+    }
     a.wide_ok = klass_hint == 1;          // 1 = decode step: rows are independent sequences
     if (W8 && ws) {                       // e4m3 copy of the same weights: only the weight-stream kernels (M <= 32) take it
         a.W8 = W8; a.wscale = ws;
@@ -405,7 +433,7 @@ extern "C" int vz_engine_set_weight(vz_engine* e, const char* name, const void* 
     VZ_CHECK_ARG(((uintptr_t)d_ptr & 15) == 0, "set_weight: '%s' must be 16-byte aligned", name);
     RC(drop_decode_graph(e));
     e->w[name] = Weight{d_ptr, dtype, n_elems};
-    e->finalized = false;
+    e->finalized = false; e->tiled_dirty = true;
     return VZ_OK;
 }
 
@@ -414,7 +442,7 @@ extern "C" int vz_engine_unset_weight(vz_engine* e, const char* name) {
     VZ_CHECK_ARG(e && name, "unset_weight: bad argument");
     RC(drop_decode_graph(e));
     e->w.erase(name);
-    e->finalized = false;
+    e->finalized = false; e->tiled_dirty = true;
     return VZ_OK;
 }
 

@@ -458,7 +458,9 @@ int vz_launch_gemm_batched(const BatchedGemmArgs& b, hipStream_t s) {
 }
 
 int vz_launch_linear(const LinearArgs& a, hipStream_t s) {
-    if (g_skinny_mode && vz_skinny_ok(a)) return vz_launch_skinny(a, s);      // 2..16 rows (batched decode): one MFMA per KiB of weights
+    // 2 rows: the GEMV with both rows in LDS streams the weights like the 1-row launch (3.12 vs 3.48 ms per 2-row step); 3..64 rows
+    // (batched decode): one MFMA per KiB of weights
+    if (g_skinny_mode && vz_skinny_ok(a) && !(a.M == 2 && g_skinny_mode != 7 && vz_gemv_ok(a))) return vz_launch_skinny(a, s);
     if (vz_gemv_ok(a)) return vz_launch_gemv(a, s);
     VZ_CHECK_ARG(!a.W8, "linear: e4m3 weights are streamed by the M <= 16 kernels only (M=%d K=%d)", a.M, a.K);
     return vz_launch_gemm(a, s);

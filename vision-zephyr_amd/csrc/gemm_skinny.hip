@@ -35,6 +35,7 @@ struct SkinnyParams {
     const bf16_t* A; const bf16_t* W; void* C;
     const float* bias; const bf16_t* residual; const float* norm_w;
     const unsigned char* W8; const float* wscale;     // FP8 instantiation: e4m3 rows [N][ldw bytes] + fp32 2^e per row (vz_hip/quant.py)
+    const bf16_t* Wt;                                 // bf16 weights in fragment order (tile_weights_kernel), or null: row-major W
     int M, N, K, lda, ldw, ldc, ldr;
     int act, out_fp32;
     float norm_eps;
@@ -59,6 +60,43 @@ __device__ __forceinline__ void widen_fp8(const u32x4 w, u32x4& lo, u32x4& hi) {
     hi = (u32x4){fp8x2_bf16x2(w2, false), fp8x2_bf16x2(w2, true), fp8x2_bf16x2(w3, false), fp8x2_bf16x2(w3, true)};
 }
 
+// Fragment-tiled weights: the 16 bytes lane (r = lane & 15, g = lane >> 4) feeds to MFMA j (0, 1) of 64-k step s of row group G -
+// W[16 G + r][64 s + 16 g + 8 j .. + 7] - sit at Wt[(((G * S + s) * 2 + j) * 64 + lane) * 8], S = K / 64: every wave-instruction of the
+// weight stream reads 1 KiB contiguous (row-major: 16 rows x 64 bytes), values and k order unchanged - results are bit-identical.
+__global__ __launch_bounds__(256) void tile_weights_kernel(const bf16_t* __restrict__ W, int ldw, bf16_t* __restrict__ Wt, int N, int K) {
+    const int S = K >> 6;
+    const long total = (long)(N >> 4) * S * 128;          // 16-byte chunks
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int lane = (int)(i & 63), j = (int)((i >> 6) & 1);
+        const long gs = i >> 7;
+        const int s = (int)(gs % S), G = (int)(gs / S);
+        const int r = lane & 15, g = lane >> 4;
+        *(uint4*)(Wt + i * 8) = *(const uint4*)(W + (size_t)(16 * G + r) * ldw + 64 * s + 16 * g + 8 * j);
+    }
+}
+
+// per-lane base, step stride and second-half offset (elements) of the weight stream in either layout
+struct WAddr { const bf16_t* a; const bf16_t* b; int sstr, hoff; };
+template <bool SWIGLU>
+__device__ __forceinline__ WAddr waddr(const SkinnyParams& p, int grp, int lane) {
+    const int fr = lane & 15, g = lane >> 4;
+    WAddr w;
+    if (p.Wt) {
+        const size_t per_group = (size_t)(p.K >> 6) * 1024;
+        w.a = p.Wt + (size_t)(SWIGLU ? 2 * grp : grp) * per_group + lane * 8;
+        w.b = w.a + per_group;
+        w.sstr = 1024; w.hoff = 512;
+    } else {
+        int row_a, row_b = 0;
+        if (SWIGLU) { row_a = grp * 32 + fr; row_b = row_a + 16; }
+        else { row_a = grp * 16 + fr; row_a = row_a < p.N ? row_a : p.N - 1; }
+        w.a = p.W + (size_t)row_a * p.ldw + g * 16;
+        w.b = p.W + (size_t)row_b * p.ldw + g * 16;
+        w.sstr = 64; w.hoff = 8;
+    }
+    return w;
+}
+
 template <bool SWIGLU, bool NORM, int NW, bool FP8 = false>
 __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -74,8 +112,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     int row_a, row_b = 0;                                                  // row this lane streams (tile a; SwiGLU: tile b = up)
     if (SWIGLU) { row_a = grp * 32 + fr; row_b = row_a + 16; }
     else { row_a = grp * 16 + fr; row_a = row_a < p.N ? row_a : p.N - 1; }
-    const bf16_t* wa = p.W + (size_t)row_a * p.ldw + g * 16;
-    const bf16_t* wb = p.W + (size_t)row_b * p.ldw + g * 16;
+    const WAddr wad = waddr<SWIGLU>(p, grp, lane);
+    const bf16_t* wa = wad.a;
+    const bf16_t* wb = wad.b;
+    const int sstr = wad.sstr, hoff = wad.hoff;
     const unsigned char* wa8 = p.W8 + (size_t)row_a * p.ldw + g * 16;      // FP8: 16 bytes = the same 16 k of a step
     const unsigned char* wb8 = p.W8 + (size_t)row_b * p.ldw + g * 16;
 
@@ -98,11 +138,11 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
                     qa[u][0] = *(const u32x4*)(wa8 + (size_t)s * 64);
                     if (SWIGLU) qb[u][0] = *(const u32x4*)(wb8 + (size_t)s * 64);
                 } else {
-                    const u32x4* pa = (const u32x4*)(wa + (size_t)s * 64);
-                    qa[u][0] = pa[0]; qa[u][1] = pa[1];        // default cache policy: the two halves of a line are requested by two instructions
+                    const bf16_t* pa = wa + (size_t)s * sstr;
+                    qa[u][0] = *(const u32x4*)pa; qa[u][1] = *(const u32x4*)(pa + hoff);        // default cache policy (tiled copy: non-temporal measured equal)
                     if (SWIGLU) {
-                        const u32x4* pb = (const u32x4*)(wb + (size_t)s * 64);
-                        qb[u][0] = pb[0]; qb[u][1] = pb[1];
+                        const bf16_t* pb = wb + (size_t)s * sstr;
+                        qb[u][0] = *(const u32x4*)pb; qb[u][1] = *(const u32x4*)(pb + hoff);
                     }
                 }
                 if (!NORM) {
@@ -222,8 +262,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_wide_kernel(SkinnyParams p) {
     int row_a, row_b = 0;                                                  // row this lane streams (tile a; SwiGLU: tile b = up)
     if (SWIGLU) { row_a = grp * 32 + fr; row_b = row_a + 16; }
     else { row_a = grp * 16 + fr; row_a = row_a < p.N ? row_a : p.N - 1; }
-    const bf16_t* wa = p.W + (size_t)row_a * p.ldw + g * 16;
-    const bf16_t* wb = p.W + (size_t)row_b * p.ldw + g * 16;
+    const WAddr wad = waddr<SWIGLU>(p, grp, lane);
+    const bf16_t* wa = wad.a;
+    const bf16_t* wb = wad.b;
+    const int sstr = wad.sstr, hoff = wad.hoff;
     const unsigned char* wa8 = p.W8 + (size_t)row_a * p.ldw + g * 16;      // FP8: 16 bytes = the same 16 k of a step
     const unsigned char* wb8 = p.W8 + (size_t)row_b * p.ldw + g * 16;
 
@@ -250,11 +292,11 @@ __global__ __launch_bounds__(NW * 64) void skinny_wide_kernel(SkinnyParams p) {
                     qa[u][0] = *(const u32x4*)(wa8 + (size_t)s * 64);
                     if (SWIGLU) qb[u][0] = *(const u32x4*)(wb8 + (size_t)s * 64);
                 } else {
-                    const u32x4* pa = (const u32x4*)(wa + (size_t)s * 64);
-                    qa[u][0] = pa[0]; qa[u][1] = pa[1];
+                    const bf16_t* pa = wa + (size_t)s * sstr;
+                    qa[u][0] = *(const u32x4*)pa; qa[u][1] = *(const u32x4*)(pa + hoff);        // default cache policy (tiled copy: non-temporal measured equal)
                     if (SWIGLU) {
-                        const u32x4* pb = (const u32x4*)(wb + (size_t)s * 64);
-                        qb[u][0] = pb[0]; qb[u][1] = pb[1];
+                        const bf16_t* pb = wb + (size_t)s * sstr;
+                        qb[u][0] = *(const u32x4*)pb; qb[u][1] = *(const u32x4*)(pb + hoff);
                     }
                 }
 #pragma unroll
@@ -374,12 +416,10 @@ __global__ __launch_bounds__(512) void skinny_persist_kernel(SkinnyParams p, int
                 qa[u][0] = *(const u32x4*)(p.W8 + (size_t)row_a * p.ldw + koff);
                 if (SWIGLU) qb[u][0] = *(const u32x4*)(p.W8 + (size_t)row_b * p.ldw + koff);
             } else {
-                const u32x4* pa = (const u32x4*)(p.W + (size_t)row_a * p.ldw + koff);
-                qa[u][0] = pa[0]; qa[u][1] = pa[1];        // default cache policy (non-temporal: 62.5 vs 57.8 us on gate-up at 16 rows)
-                if (SWIGLU) {
-                    const u32x4* pb = (const u32x4*)(p.W + (size_t)row_b * p.ldw + koff);
-                    qb[u][0] = pb[0]; qb[u][1] = pb[1];
-                }
+                const WAddr wad = waddr<SWIGLU>(p, grp, lane);
+                const size_t so = (size_t)(s0 + ps) * wad.sstr;
+                qa[u][0] = *(const u32x4*)(wad.a + so); qa[u][1] = *(const u32x4*)(wad.a + so + wad.hoff);        // default cache policy (non-temporal: 62.5 vs 57.8 us on gate-up at 16 rows)
+                if (SWIGLU) { qb[u][0] = *(const u32x4*)(wad.b + so); qb[u][1] = *(const u32x4*)(wad.b + so + wad.hoff); }
             }
             if (++ps == per) { ps = 0; ++pj; }
         }
@@ -560,6 +600,16 @@ int vz_init_skinny_kernels() {
     return VZ_OK;
 }
 
+int vz_launch_tile_weights(const bf16_t* W, int N, int K, int ldw, bf16_t* Wt, hipStream_t s) {
+    VZ_CHECK_ARG(W && Wt && N > 0 && (N & 15) == 0 && K >= 64 && (K & 63) == 0 && ldw >= K && (ldw & 7) == 0 &&
+                 ((uintptr_t)W & 15) == 0 && ((uintptr_t)Wt & 15) == 0, "tile_weights: needs N %% 16 == 0, K %% 64 == 0, 16-byte-aligned rows (N=%d K=%d)", N, K);
+    const long chunks = (long)(N >> 4) * (K >> 6) * 128;
+    const int blocks = (int)std::min<long>((chunks + 255) / 256, 8192);
+    hipLaunchKernelGGL(tile_weights_kernel, dim3(blocks), dim3(256), 0, s, W, ldw, Wt, N, K);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
 int vz_launch_skinny(const LinearArgs& a, hipStream_t s) {
     int rc = vz_linear_check_common(a);
     if (rc) return rc;
@@ -568,6 +618,7 @@ int vz_launch_skinny(const LinearArgs& a, hipStream_t s) {
     SkinnyParams p;
     p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.residual = a.residual; p.norm_w = a.norm_w;
     p.W8 = a.W8; p.wscale = a.wscale;
+    p.Wt = (!a.W8 && (a.N & 15) == 0 && g_skinny_mode != 5) ? a.Wt : nullptr;        // (knob 9 = 5: ignore the tiled copies, A/B)
     p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr;
     p.act = a.act; p.out_fp32 = a.out_fp32; p.norm_eps = a.norm_eps;
     const bool sw = a.act == VZ_ACT_SWIGLU;

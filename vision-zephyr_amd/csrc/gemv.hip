@@ -303,17 +303,17 @@ int launch_mb(const GemvParams& p, hipStream_t s, size_t lds) {
     // gate-up / lm_head: 512 looping) - measured 337 vs 331 tok/s end to end (GEMV 5.67 vs 5.56 TB/s): fewer, fatter workgroups whose
     // waves start together burst together.  QKV (3072 units = 384 such workgroups = 1.5 per CU) keeps 768 4-wave workgroups.
     bool fat = false;
-    if constexpr (MB == 1) {
+    if constexpr (MB <= 4) {
         const int units = p.act == VZ_ACT_SWIGLU ? p.N / 2 : (p.N + 1) / 2;
         const int b8 = (units + 7) / 8;
         fat = g_gemv_variant == 0 && (b8 >= 512 || b8 % 256 == 0);
     }
     if (p.W8) {       // 2 rows x up to 8 chunks of 1024 k per wave (measured faster than 4 rows x 4: 13.5 vs 15.3 us on down-proj)
         if (g_gemv_variant == 1) return launch_variant<MB, 4, 4, true, true>(p, s, lds);
-        if constexpr (MB == 1) { if (fat) return launch_variant<MB, 2, 8, true, true, 8>(p, s, lds); }
+        if constexpr (MB <= 4) { if (fat) return launch_variant<MB, 2, 8, true, true, 8>(p, s, lds); }
         return launch_variant<MB, 2, 8, true, true>(p, s, lds);
     }
-    if constexpr (MB == 1) { if (fat) return launch_variant<MB, 2, 8, true, false, 8>(p, s, lds); }
+    if constexpr (MB <= 4) { if (fat) return launch_variant<MB, 2, 8, true, false, 8>(p, s, lds); }
     switch (g_gemv_variant) {
         case 1: return launch_variant<MB, 2, 4, false>(p, s, lds);
         case 2: return launch_variant<MB, 2, 8, false>(p, s, lds);
@@ -348,6 +348,10 @@ int vz_init_gemv_kernels() {
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<1, 2, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<1, 2, 8, true, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<1, 2, 8, true, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<2, 2, 8, true, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<2, 2, 8, true, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<4, 2, 8, true, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<4, 2, 8, true, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<2, 2, 8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<2, 2, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<4, 2, 8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));

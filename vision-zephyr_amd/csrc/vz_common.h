@@ -121,6 +121,9 @@ struct LinearArgs {
     const float* norm_w; float norm_eps;
     // optional e4m3 copy of W (rows [N][ldw] bytes) + one fp32 power-of-two scale per row: GEMV path streams these instead
     const unsigned char* W8 = nullptr; const float* wscale = nullptr;
+    // optional MFMA-fragment-tiled copy of W (vz_launch_tile_weights: [N/16][K/64][2][64 lanes][8]): the 2..64-row weight stream
+    // (gemm_skinny.hip) then reads 1 KiB contiguous per wave-instruction instead of 16 rows x 64 bytes; same values, same k order
+    const bf16_t* Wt = nullptr;
     // 17..64 rows may take the MFMA weight stream (rows = independent sequences of a decode batch).  Off for the engine's prefill /
     // Q-Former linears: there a row's result must not depend on how many rows sit beside it (the tile GEMM's split-K is a
     // function of N and K only; tests/test_stages_gpu.py::test_qformer), and 32 / 64 / 96 rows must all take the same kernel.
@@ -132,6 +135,7 @@ struct LinearArgs {
     int* err = nullptr;
 };
 int vz_launch_gemm(const LinearArgs& a, hipStream_t s);
+int vz_launch_tile_weights(const bf16_t* W, int N, int K, int ldw, bf16_t* Wt, hipStream_t s);
 int vz_linear_check_common(const LinearArgs& a);
 bool vz_gemv_ok(const LinearArgs& a);
 bool vz_skinny_ok(const LinearArgs& a);      // 2..16 rows: MFMA weight stream (gemm_skinny.hip)

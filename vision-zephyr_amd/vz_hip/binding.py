@@ -44,6 +44,8 @@ SYMBOLS = {
     "vz_abi_version": (_I, []),
     "vz_target_arch": (C.c_char_p, []),
     "vz_op_linear": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "vz_op_tile_weights": (_I, [_P, _I, _I, _I, _P, _P]),
+    "vz_op_linear_tiled": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _F, _P]),
     "vz_op_linear_impl": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "vz_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _P]),
     "vz_op_rmsnorm": (_I, [_P, _I, _P, _I, _P, _I, _I, _F, _P]),
@@ -180,6 +182,29 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: int 
         check(lib().vz_op_linear(*args))
     else:
         check(lib().vz_op_linear_impl(impl, *args))
+    return out
+
+
+def tile_weights(w: torch.Tensor) -> torch.Tensor:
+    """fragment-tiled copy of a dense bf16 [N, K] weight for the 2..64-row MFMA weight stream (layout: include/viszephyr.h)."""
+    _need_cuda(w)
+    assert w.dtype == torch.bfloat16 and w.dim() == 2 and w.stride(1) == 1
+    wt = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+    check(lib().vz_op_tile_weights(ptr(w), w.shape[0], w.shape[1], w.stride(0), ptr(wt), stream_ptr(w.device)))
+    return wt
+
+
+def linear_tiled(x: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, bias=None, residual=None, act: int = ACT_NONE, out_fp32=False,
+                 norm_w=None, norm_eps: float = 0.0) -> torch.Tensor:
+    """the MFMA weight stream (2 <= M <= 64) reading the tiled copy `wt` of w; bit-identical to linear(impl=3)."""
+    _need_cuda(x, w, wt, bias, residual, norm_w)
+    M, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    out = torch.empty(M, n_out, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=x.device)
+    check(lib().vz_op_linear_tiled(ptr(x), x.stride(0), ptr(w), ptr(wt), w.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias),
+                                   ptr(residual), 0 if residual is None else residual.stride(0), act, int(out_fp32), ptr(norm_w),
+                                   float(norm_eps), stream_ptr(x.device)))
     return out
 
 

@@ -14,6 +14,7 @@ Vectors (biases, LayerNorm/RMSNorm scales) are fp32.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import re
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -92,6 +93,11 @@ class Engine:
         """the e4m3 copy + row scales of a bf16 decode weight are derived data: whoever rewrites (or replaces) the bf16 tensor
         invalidates them, so that finalize() re-quantises (a second load_weights / LoRA re-merge / resize_vocab on a
         weight_fp8 engine must not leave decode streaming the OLD e4m3 rows)."""
+        nt = name + "t"
+        if nt in self.w:                      # the fragment-tiled copy of a bf16 decode weight (bf16 engines)
+            del self.w[nt]
+            self._registered.discard(nt)
+            B.check(self.lib.vz_engine_unset_weight(self.h, nt.encode()))
         if not (self.weight_fp8 and self._FP8_NAMES.match(name)):
             return
         for n in self._fp8_names(name):
@@ -336,9 +342,23 @@ class Engine:
             self.w[n8], self.w[ns] = w8.contiguous(), scale.contiguous()
             self._registered.discard(name)
 
+    def _tile_decode_weights(self):
+        """bf16 engines: every decode-side Zephyr linear gets a copy in MFMA-fragment order (vz_op_tile_weights; +14.5 GB for
+        Zephyr-7B) that the 2..64-row decode steps stream with 1-KiB wave-instructions; same values, same k order as the
+        row-major tensor the prefill GEMMs and the 1-row GEMV keep using.  VZ_DECODE_TILED=0 turns it off."""
+        if os.environ.get("VZ_DECODE_TILED", "1") == "0":
+            return
+        for name in [n for n in self.w if self._FP8_NAMES.match(n)]:
+            w = self.w[name]
+            if name + "t" in self.w or w.shape[0] % 16 or w.shape[1] % 64:
+                continue
+            self.w[name + "t"] = B.tile_weights(w)
+
     def finalize(self):
         if self.weight_fp8:
             self._quantize_decode_weights()
+        elif self.max_batch > 1:
+            self._tile_decode_weights()
         for name, t in self.w.items():
             if name in self._registered:
                 continue
