@@ -535,8 +535,12 @@ def test_skinny_gemm(B, M, N, K, act):
     # rows are independent: every row equals what it gets in a 2-row launch (batch invariance of the decode path)
     pair = B.linear(x[:2].contiguous(), w, act=act, out_fp32=True, impl=3)
     assert torch.equal(pair, out32[:2])
-    # the production dispatch takes this path for 2..16 rows
-    assert torch.equal(B.linear(x, w, act=act, out_fp32=True), out32)
+    # the production dispatch takes this path for 3..16 rows; 2 rows go to the GEMV (both rows in LDS: it streams like a 1-row launch)
+    prod = B.linear(x, w, act=act, out_fp32=True)
+    if M == 2:
+        check_close(f"2-row GEMV vs MFMA stream {N}x{K} act{act}", prod, out32, 1e-4, 1e-4)
+    else:
+        assert torch.equal(prod, out32)
 
 
 @pytest.mark.parametrize("M,act", [(2, 0), (4, 3), (9, 0), (16, 3)])
@@ -549,8 +553,12 @@ def test_skinny_gemm_fused_rmsnorm(B, M, act):
     xn = (nw.double() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))).float().bfloat16()
     out = B.linear_rmsnorm(x, nw, 1e-5, w, act=act, out_fp32=True)
     check_close(f"skinny fused rmsnorm M{M} act{act}", out, _ref_linear(xn, w, None, None, act), 2e-2, 3e-3)
-    # exactly the stand-alone norm kernel followed by the same GEMM
-    assert torch.equal(out, B.linear(B.rmsnorm(x, nw, 1e-5), w, act=act, out_fp32=True, impl=3))
+    # exactly the stand-alone norm kernel followed by the same GEMM (2 rows: the production dispatch is the GEMV with its own fused norm)
+    unfused = B.linear(B.rmsnorm(x, nw, 1e-5), w, act=act, out_fp32=True, impl=3)
+    if M == 2:
+        check_close("2-row GEMV fused norm vs norm + MFMA stream", out, unfused, 1e-4, 1e-4)
+    else:
+        assert torch.equal(out, unfused)
     # and, with the knob off, the GEMV path fuses the norm the same way (M <= 8)
     if M <= 8:
         try:
@@ -780,10 +788,38 @@ def test_skinny_tiled_weights_bit_identical(B, M, N, K, act, norm):
     n_out = N // 2 if act == 3 else N
     res = _rand((M, n_out), 1.0, 92).bfloat16()
     nw = (_rand((K,), 0.2, 93) + 1.0) if norm and M <= 16 else None
-    if nw is not None:
-        a = B.linear_rmsnorm(x, nw, 1e-5, w, residual=res, act=act)
-        b = B.linear_tiled(x, w, wt, residual=res, act=act, norm_w=nw, norm_eps=1e-5)
-    else:
-        a = B.linear(x, w, residual=res, act=act, impl=3)
-        b = B.linear_tiled(x, w, wt, residual=res, act=act)
+    try:
+        B.check(B.lib().vz_tune_set(19, 0))          # 17..64 rows: keep linear_tiled on the MFMA weight stream (not gemm_wide.hip)
+        if nw is not None and M > 2:
+            a = B.linear_rmsnorm(x, nw, 1e-5, w, residual=res, act=act)
+            b = B.linear_tiled(x, w, wt, residual=res, act=act, norm_w=nw, norm_eps=1e-5)
+        else:                                        # (2 rows with a fused norm: the production dispatch is the GEMV)
+            a = B.linear(x, w, residual=res, act=act, impl=3)
+            b = B.linear_tiled(x, w, wt, residual=res, act=act)
+    finally:
+        B.check(B.lib().vz_tune_set(19, 1))
     assert torch.equal(a, b), f"max diff {float((a.float() - b.float()).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("M,N,K,act", [(17, 4096, 4096, 0), (32, 6144, 4096, 0), (24, 28672, 4096, 3), (32, 4096, 14336, 0), (33, 4096, 4096, 1),
+                                       (64, 6144, 4096, 0), (64, 28672, 4096, 3), (50, 4096, 14336, 0), (64, 32000, 4096, 0), (48, 3584, 4096, 3)])
+def test_wide_tiled_gemm(B, M, N, K, act):
+    """gemm_wide.hip (17..64-row decode steps): eight row groups per workgroup on the tiled weight copy, the activations of a 512-k chunk
+    staged once in LDS, K splits (P = 8 / 4 / 1 / 7 for these shapes) combined by the last arriver.  Against the fp64 reference through
+    bias / activation / SwiGLU / residual, bf16 and fp32 outputs; the split-K sum is in split order: two launches agree bit for bit,
+    and rows do not depend on the rows beside them (same row-block count class: 17..32 or 33..64)."""
+    x = _rand((M, K), 1.0, 401).bfloat16()
+    w = (_rand((N, K), 1.0, 402) * K ** -0.5).bfloat16()
+    wt = B.tile_weights(w)
+    n_out = N // 2 if act == 3 else N
+    bias = None if act == 3 else _rand((N,), 0.1, 403)
+    res = _rand((M, n_out), 0.5, 404).bfloat16()
+    out32 = B.linear_tiled(x, w, wt, bias=bias, residual=res, act=act, out_fp32=True)
+    check_close(f"wide tiled fp32 M{M} N{N} K{K} act{act}", out32, _ref_linear(x, w, bias, res, act), 1e-4, 1e-4)
+    out = B.linear_tiled(x, w, wt, bias=bias, residual=res, act=act)
+    check_close(f"wide tiled bf16 M{M} N{N} K{K} act{act}", out, _ref_linear(x, w, bias, res, act), BF16_MAX, BF16_L2)
+    for _ in range(3):
+        assert torch.equal(B.linear_tiled(x, w, wt, bias=bias, residual=res, act=act, out_fp32=True), out32)
+    lo = 17 if M <= 32 else 33
+    head = B.linear_tiled(x[:lo].contiguous(), w, wt, bias=bias, residual=res[:lo].contiguous(), act=act, out_fp32=True)
+    assert torch.equal(head, out32[:lo])

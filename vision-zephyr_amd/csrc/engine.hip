@@ -98,6 +98,7 @@ extern "C" int vz_op_linear_tiled(const void* A, int lda, const void* W, const v
     VZ_CHECK_ARG(Wt && ldw == K && (N & 15) == 0, "linear_tiled: needs the tiled copy of a dense [N, K] weight with N %% 16 == 0");
     LinearArgs a = mk_linear(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, act, out_fp32);
     a.Wt = (const bf16_t*)Wt; a.norm_w = norm_w; a.norm_eps = norm_eps;
+    if (M >= 17 && vz_wide_ok(a)) return vz_launch_wide(a, (hipStream_t)s);          // 17..64 rows: gemm_wide.hip
     VZ_CHECK_ARG(g_skinny_mode && vz_skinny_ok(a), "linear_tiled: the MFMA weight stream takes 2 <= M <= 64 (fused norm: <= 16), K %% 64 == 0 (M=%d K=%d)", M, K);
     return vz_launch_skinny(a, (hipStream_t)s);
 }
@@ -288,6 +289,23 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
         LinearArgs t = a;
         if (M > 16) t.norm_w = nullptr;   // 17..32 rows: the norm runs as its own kernel below
         if (!vz_gemv_ok(t) && !(g_skinny_mode && vz_skinny_ok(t))) { a.W8 = nullptr; a.wscale = nullptr; }
+    }
+    if (klass_hint == 1 && M >= 17 && M <= 64 && a.Wt && !(W8 && ws)) {
+        // 17..64-row decode step on the tiled weight copy (gemm_wide.hip): weights straight to registers, the activations of a 512-k
+        // chunk staged once per 128 weight rows - for the projections whose row blocks fill the chip without a K split (gate|up,
+        // lm_head: measured 52.7 vs 62 us and 55 vs 91 us at 64 rows; the split shapes stay on the tile GEMM).  The RMSNorm runs
+        // as its own launch.
+        LinearArgs t = a;
+        if (norm_w) { t.A = e->d_xnorm; t.lda = K; t.norm_w = nullptr; }
+        if (vz_wide_engine_ok(t)) {
+            if (norm_w) {
+                ProfScope ps(e, K_NORM, s);
+                int r = vz_launch_rmsnorm(A, lda, e->d_xnorm, K, norm_w, M, K, norm_eps, s);
+                if (r) return r;
+            }
+            ProfScope ps(e, K_GEMV, s);
+            return vz_launch_wide(t, s);
+        }
     }
     if (klass_hint == 1 && M >= ((W8 && ws) ? std::max(g_decode_tile_rows, 33) : g_decode_tile_rows) && M <= 64 && g_skinny_mode && (K & 63) == 0) {     // (e4m3 stream: ahead up to 32 rows)
         // 17..64-row decode step as a TILE GEMM: the 128^2 MFMA kernel streams every weight once at the rate its workgroups can pull
@@ -1173,6 +1191,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 9) { g_skinny_mode = value; return VZ_OK; }
     if (knob == 11) { g_gemm256_drain = value; return VZ_OK; }
     if (knob == 14) { g_decode_tile_rows = value; return VZ_OK; }
+    if (knob == 19) { g_wide_mode = value; return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }
     if (knob == 10) { if (value < 0 || value > 64) { vz_set_error("tune_set: decode attention splits must be 0..64"); return VZ_ERR_ARG; } g_attn_nsplit = value; return VZ_OK; }

@@ -1,0 +1,317 @@
+// Weight-streaming MFMA GEMM for 17..64 activation rows (wide decode batches): C[M <= 64, N'] = epi(x[M,K] . W[N,K]^T), gfx950.
+//
+// A 64-row decode step still reads every weight once, so the bound is the HBM stream (436 MB per Zephyr layer = 69 us at
+// 6.3 TB/s); what the two earlier routes lose is the ACTIVATION side:
+//   * gemm_skinny.hip's wide kernel gives one 16-row weight group to a workgroup whose waves split K: every workgroup pulls all
+//     64 x K activations from L2 - 4 bytes of x per byte of W - and falls to 2.7 TB/s of weights at 64 rows;
+//   * the 128^2 tile GEMM (gemm.hip, split-K) pads the rows to 128, keeps one 32-KiB stage in flight per workgroup and needs a
+//     finalize launch per projection (gate|up 58 us = 4.0 TB/s, + 5-6 us each).
+// Here a workgroup owns EIGHT weight row groups (128 rows; SwiGLU: 4 gate + 4 up groups = 64 outputs) over a K slice:
+//   * wave w streams group w's fragment-tiled weights (vz_launch_tile_weights: 1 KiB contiguous per wave-instruction) straight
+//     into registers, 8 steps (16 KiB) in flight per wave, refilled slot by slot across chunk boundaries;
+//   * the activations of a 512-k chunk (64 rows x 512 k = 64 KiB) are staged ONCE per workgroup into LDS in B-fragment order
+//     (every ds_read_b128 of a fragment is 1 KiB contiguous: conflict-free) and feed all eight waves - a quarter of a byte of x
+//     from L2 per byte of W; double-buffered, one barrier per chunk;
+//   * K can be split over P workgroups where N / 128 row blocks cannot fill the chip.  The P partial tiles meet WITHOUT a
+//     finalize launch and without a device-side wait: write-through (sc1) partials, drained, one relaxed agent-scope ticket per
+//     row block, the LAST arriver sums the P partials in split order (deterministic) and runs the epilogue (CDNA4 guide section
+//     6 G16: "sc1 payload + drained ticket, last arriver told by the value its add returned").
+// Measured at 64 rows inside a 32-layer step (tools/prof_batched.sh, profiles/r02_rows.txt): gate|up (224 workgroups, no split) 52.7 us
+// against 57.1 + 5.2 (tile GEMM + finalize), lm_head 55 against 79 + 12; the split shapes do NOT win - down (P = 7) 38.5 against
+// 28.9 + 6.2, O (P = 8 / 4) 22.9 against 14.2 + 6.2, QKV (P = 4) 22.2 against 17.0 + 4.9 - so the engine takes this kernel where
+// pick_splits() = 1 and keeps the tile GEMM elsewhere (vz_wide_engine_ok).  The stream alone (MFMAs and LDS reads removed) ran
+// at the same rate: what bounds it is the load side of one 8-wave workgroup per CU, not the compute.
+// k assignment inside a 64-k step is gemm_skinny.hip's (lane (r, g): k = 16 g .. 16 g + 7 | + 8 .. + 15), so the tiled copies are shared.
+// The split-K workspace (partials + tickets) is process-wide like the tile GEMM's slab: launches must be stream-ordered (every
+// engine call site is single-stream).
+#include <algorithm>
+
+#include "vz_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr int CH = 8;                      // 64-k steps per activation chunk (512 k)
+constexpr int NWV = 8;                     // waves per workgroup = weight row groups per workgroup
+
+struct WideParams {
+    const bf16_t* A; const bf16_t* Wt; void* C;
+    const float* bias; const bf16_t* residual;
+    int M, N, K, lda, ldc, ldr;
+    int act, out_fp32;
+    int P, cps;                            // K splits; chunks per split (K / 64 == P * cps * CH)
+    float* part; unsigned* ticket;         // P > 1: partial tiles [rb][P][wave][MH][64] f32x4, one ticket per row block
+};
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// 8-byte write-through store / L2-bypassing load at agent scope (global_store / load_dwordx2 sc1)
+__device__ __forceinline__ void st2_sc1(float* p, float a, float b) {
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x2 ld2_sc1(const float* p) {
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (f32x2){__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32))};
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == VZ_ACT_QUICK_GELU) return act_quick_gelu(v);
+    if (act == VZ_ACT_GELU_ERF) return act_gelu_erf(v);
+    return v;
+}
+
+// MH = 16-row activation blocks (2: up to 32 rows, 4: up to 64)
+template <int MH, bool SWIGLU>
+__global__ __launch_bounds__(NWV * 64) void wide_tiled_kernel(WideParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // Xs[2][CH][2][MH][64 lanes] x 16 B
+    constexpr int QN = CH * 2 * MH;                                   // 1-KiB fragments per chunk
+    constexpr int XL = QN / NWV;                                      // staged by each wave per chunk
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int rb = blockIdx.x, sp = blockIdx.y;
+    const int S = p.K >> 6;
+    // this wave's weight row group: plain: 8 consecutive groups; SwiGLU ([16 gate | 16 up] interleaved rows): waves 0..3 the gate
+    // groups of output blocks 4 rb .. 4 rb + 3, waves 4..7 their up groups
+    const int G = SWIGLU ? 2 * (rb * 4 + (wave & 3)) + (wave >> 2) : rb * NWV + wave;
+    const int step0 = sp * p.cps * CH;
+    const bf16_t* wa = p.Wt + ((size_t)G * S + step0) * 1024 + lane * 8;
+
+    // ---- weight ring: slot u holds step u of the current chunk, refilled with the next chunk's step u once its MFMAs are issued
+    //      (16 KiB per wave in flight; a second bank - 32 KiB - and non-temporal loads both measured no faster) ----
+    u32x4 qa[CH][2];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        qa[u][0] = *(const u32x4*)(wa + (size_t)u * 1024);
+        qa[u][1] = *(const u32x4*)(wa + (size_t)u * 1024 + 512);
+    }
+
+    // ---- activation staging: fragment q = (s * 2 + j) * MH + h of a chunk holds, for lane (m = fr, g), x[16 h + m][64 s + 16 g + 8 j .. + 7]
+    //      (rows past M repeat row M - 1: their outputs are never stored) ----
+    const bf16_t* xsrc[XL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int q = wave + NWV * i;
+        const int h = q % MH, j = (q / MH) & 1, s = q / (2 * MH);
+        const int row = min(16 * h + fr, p.M - 1);
+        xsrc[i] = p.A + (size_t)row * p.lda + (size_t)(step0 + s) * 64 + 16 * g + 8 * j;
+    }
+    u32x4 xr[XL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) xr[i] = *(const u32x4*)xsrc[i];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) *(u32x4*)(smem + ((size_t)(wave + NWV * i) * 64 + lane) * 16) = xr[i];
+    __syncthreads();
+
+    f32x4 acc[MH];
+#pragma unroll
+    for (int h = 0; h < MH; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int buf = 0;
+    for (int c = 0; c < p.cps; ++c) {
+        const bool more = c + 1 < p.cps;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < XL; ++i) xr[i] = *(const u32x4*)(xsrc[i] + (size_t)(c + 1) * CH * 64);
+        }
+        const char* xs = smem + (size_t)buf * QN * 1024 + lane * 16;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+#pragma unroll
+            for (int h = 0; h < MH; ++h) {
+                const u32x4 b0 = *(const u32x4*)(xs + (size_t)((u * 2 + 0) * MH + h) * 1024);
+                const u32x4 b1 = *(const u32x4*)(xs + (size_t)((u * 2 + 1) * MH + h) * 1024);
+                acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qa[u][0]), as_bf16x8(b0), acc[h], 0, 0, 0);
+                acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qa[u][1]), as_bf16x8(b1), acc[h], 0, 0, 0);
+            }
+            if (more) {
+                const bf16_t* wn = wa + (size_t)((c + 1) * CH + u) * 1024;
+                qa[u][0] = *(const u32x4*)wn;
+                qa[u][1] = *(const u32x4*)(wn + 512);
+            }
+        }
+        if (more) {
+            char* xd = smem + (size_t)(buf ^ 1) * QN * 1024;
+#pragma unroll
+            for (int i = 0; i < XL; ++i) *(u32x4*)(xd + ((size_t)(wave + NWV * i) * 64 + lane) * 16) = xr[i];
+        }
+        __syncthreads();           // chunk c + 1 is staged; everybody is done reading chunk c
+        buf ^= 1;
+    }
+
+    // ---- K splits meet: partial tiles out (write-through), one ticket per row block, the last arriver sums them in split order.
+    //      Partials are stored as [tile h][half][64 lanes][2 floats]: every 8-byte store / load instruction covers 512 contiguous bytes. ----
+    if (p.P > 1) {
+        float* mine = p.part + ((((size_t)rb * p.P + sp) * NWV + wave) * MH) * 256 + lane * 2;
+#pragma unroll
+        for (int h = 0; h < MH; ++h) {
+            st2_sc1(mine + h * 256, acc[h][0], acc[h][1]);
+            st2_sc1(mine + h * 256 + 128, acc[h][2], acc[h][3]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ unsigned last_flag;
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(p.ticket + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = (t == (unsigned)p.P - 1) ? 1u : 0u;
+            if (last_flag) __hip_atomic_store(p.ticket + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every split has arrived: ready for the next launch
+        }
+        __syncthreads();           // the wave that added joins this barrier after its add returned; everyone loads behind it
+        if (!last_flag) return;
+#pragma unroll
+        for (int h = 0; h < MH; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // four splits' tiles are requested before the first is added (hipcc waits for an atomic load right before its use: one
+        // round trip per batch instead of one per value); the additions run in split order whatever the arrival order was
+        const float* base = p.part + (((size_t)rb * p.P * NWV + wave) * MH) * 256 + lane * 2;
+        const size_t sstr = (size_t)NWV * MH * 256;
+        for (int s0 = 0; s0 < p.P; s0 += 4) {
+            f32x2 t[4][MH][2];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float* src = base + (size_t)min(s0 + d, p.P - 1) * sstr;
+#pragma unroll
+                for (int h = 0; h < MH; ++h) { t[d][h][0] = ld2_sc1(src + h * 256); t[d][h][1] = ld2_sc1(src + h * 256 + 128); }
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if (s0 + d < p.P) {
+#pragma unroll
+                    for (int h = 0; h < MH; ++h) { acc[h][0] += t[d][h][0][0]; acc[h][1] += t[d][h][0][1]; acc[h][2] += t[d][h][1][0]; acc[h][3] += t[d][h][1][1]; }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane (m = fr, g) of tile h holds outputs n = 4 g .. 4 g + 3 of this wave's group for row 16 h + m ----
+    if (SWIGLU) {
+        // up waves hand their tiles to the gate wave of the same output block through LDS (the staging buffers are free)
+        float* ex = (float*)smem;
+        if (wave >= 4) {
+#pragma unroll
+            for (int h = 0; h < MH; ++h) *(f32x4*)(ex + (((size_t)(wave - 4) * MH + h) * 64 + lane) * 4) = acc[h];
+        }
+        __syncthreads();
+        if (wave >= 4) return;
+        const int n0 = (rb * 4 + wave) * 16 + g * 4;               // output columns of block rb * 4 + wave
+#pragma unroll
+        for (int h = 0; h < MH; ++h) {
+            const int m = 16 * h + fr;
+            if (m >= p.M) continue;
+            const f32x4 up = *(const f32x4*)(ex + (((size_t)wave * MH + h) * 64 + lane) * 4);
+            float t[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                t[r] = act_silu(acc[h][r]) * up[r];
+                if (p.residual) t[r] += bf16_to_f32(p.residual[(size_t)m * p.ldr + n0 + r]);
+            }
+            if (p.out_fp32) *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n0) = (f32x4){t[0], t[1], t[2], t[3]};
+            else { uint2 pk; pk.x = pack_bf16x2(t[0], t[1]); pk.y = pack_bf16x2(t[2], t[3]); *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n0) = pk; }
+        }
+        return;
+    }
+    const int n0 = G * 16 + g * 4;
+#pragma unroll
+    for (int h = 0; h < MH; ++h) {
+        const int m = 16 * h + fr;
+        if (m >= p.M) continue;
+        float t[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t[r] = acc[h][r];
+            if (p.bias) t[r] += p.bias[n0 + r];
+            t[r] = apply_act(t[r], p.act);
+            if (p.residual) t[r] += bf16_to_f32(p.residual[(size_t)m * p.ldr + n0 + r]);
+        }
+        if (p.out_fp32) *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n0) = (f32x4){t[0], t[1], t[2], t[3]};
+        else { uint2 pk; pk.x = pack_bf16x2(t[0], t[1]); pk.y = pack_bf16x2(t[2], t[3]); *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n0) = pk; }
+    }
+}
+
+float* g_wide_part = nullptr;
+unsigned* g_wide_ticket = nullptr;
+constexpr size_t WIDE_PART_BYTES = (size_t)24 << 20;      // O: 32 row blocks x 8 splits x 32 KiB = 8 MiB; QKV 6; down 7
+constexpr int WIDE_TICKETS = 4096;
+int g_wide_cus = 256;
+
+// K splits: the fewest residency rounds of chunk-times per CU, then the fewest splits (partials cost 2 x 32 KiB per workgroup)
+int pick_splits(int row_blocks, int chunks) {
+    int best = 1; long best_cost = -1;
+    for (int P = 1; P <= chunks && P <= 32; ++P) {
+        if (chunks % P) continue;
+        const long wgs = (long)row_blocks * P;
+        const long rounds = (wgs + g_wide_cus - 1) / g_wide_cus;
+        // one chunk-time (128 KiB of weights per CU, ~5 us) = 16 units; splits: every workgroup parks 32 KiB, the last arriver pays two
+        // round trips and reads P x 32 KiB
+        const long cost = rounds * (chunks / P) * 16 + (P > 1 ? 14 + 4 * P : 0);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = P; }
+    }
+    return best;
+}
+
+}  // namespace
+
+int g_wide_mode = 1;       // vz_tune_set(19, v): 0 = off (17..64-row decode steps keep the earlier routes)
+
+// what the engine's decode steps use it for: shapes that need no K split (measured faster than the tile GEMM + finalize there only)
+bool vz_wide_engine_ok(const LinearArgs& a);
+
+bool vz_wide_ok(const LinearArgs& a) {
+    if (!g_wide_mode || !a.Wt || a.W8 || a.norm_w || !a.wide_ok) return false;
+    if (a.M < 17 || a.M > 64 || (a.N & 127) != 0 || (a.K & 511) != 0 || a.ldw != a.K) return false;
+    if ((a.lda & 7) != 0 || (a.ldc & 3) != 0 || (a.residual && (a.ldr & 3) != 0)) return false;
+    if (a.act == VZ_ACT_SWIGLU && a.bias) return false;
+    if (((uintptr_t)a.bias & 15) != 0) return false;
+    const int rbs = a.N >> 7, chunks = a.K >> 9;
+    const int P = pick_splits(rbs, chunks);
+    const int mh = a.M <= 32 ? 2 : 4;
+    return (size_t)rbs * P * NWV * mh * 1024 <= WIDE_PART_BYTES && rbs <= WIDE_TICKETS;
+}
+
+bool vz_wide_engine_ok(const LinearArgs& a) { return vz_wide_ok(a) && pick_splits(a.N >> 7, a.K >> 9) == 1; }
+
+int vz_init_wide_kernels() {
+    static bool done = false;
+    if (done) return VZ_OK;
+    VZ_CHECK_HIP(hipMalloc((void**)&g_wide_part, WIDE_PART_BYTES));
+    VZ_CHECK_HIP(hipMalloc((void**)&g_wide_ticket, WIDE_TICKETS * sizeof(unsigned)));
+    VZ_CHECK_HIP(hipMemset(g_wide_ticket, 0, WIDE_TICKETS * sizeof(unsigned)));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)wide_tiled_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CH * 2 * 2 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)wide_tiled_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CH * 2 * 2 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)wide_tiled_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CH * 2 * 4 * 1024));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)wide_tiled_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CH * 2 * 4 * 1024));
+    int dev = 0;
+    hipDeviceProp_t prop;
+    VZ_CHECK_HIP(hipGetDevice(&dev));
+    VZ_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    if (prop.multiProcessorCount > 0) g_wide_cus = prop.multiProcessorCount;
+    done = true;
+    return VZ_OK;
+}
+
+int vz_launch_wide(const LinearArgs& a, hipStream_t s) {
+    int rc = vz_linear_check_common(a);
+    if (rc) return rc;
+    { int r = vz_init_wide_kernels(); if (r) return r; }
+    VZ_CHECK_ARG(vz_wide_ok(a), "wide gemm: needs the tiled weight copy, 17 <= M <= 64, N %% 128 == 0, K %% 512 == 0, no fused norm (M=%d N=%d K=%d)", a.M, a.N, a.K);
+    WideParams p;
+    p.A = a.A; p.Wt = a.Wt; p.C = a.C; p.bias = a.bias; p.residual = a.residual;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr;
+    p.act = a.act; p.out_fp32 = a.out_fp32;
+    const int rbs = a.N >> 7, chunks = a.K >> 9;
+    p.P = pick_splits(rbs, chunks); p.cps = chunks / p.P;
+    p.part = g_wide_part; p.ticket = g_wide_ticket;
+    const bool sw = a.act == VZ_ACT_SWIGLU;
+    const dim3 grid(rbs, p.P), block(NWV * 64);
+    if (a.M <= 32) {
+        const size_t lds = 2 * CH * 2 * 2 * 1024;
+        if (sw) vz_launch_timed(wide_tiled_kernel<2, true>, grid, block, lds, s, p);
+        else vz_launch_timed(wide_tiled_kernel<2, false>, grid, block, lds, s, p);
+    } else {
+        const size_t lds = 2 * CH * 2 * 4 * 1024;
+        if (sw) vz_launch_timed(wide_tiled_kernel<4, true>, grid, block, lds, s, p);
+        else vz_launch_timed(wide_tiled_kernel<4, false>, grid, block, lds, s, p);
+    }
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}

@@ -136,6 +136,12 @@ struct LinearArgs {
 };
 int vz_launch_gemm(const LinearArgs& a, hipStream_t s);
 int vz_launch_tile_weights(const bf16_t* W, int N, int K, int ldw, bf16_t* Wt, hipStream_t s);
+// gemm_wide.hip: 17..64 rows on the tiled weight copy, activations staged once per 128 weight rows (needs a.Wt, no fused norm)
+bool vz_wide_ok(const LinearArgs& a);
+bool vz_wide_engine_ok(const LinearArgs& a);     // the shapes an engine's decode step routes there (no K split)
+int vz_launch_wide(const LinearArgs& a, hipStream_t s);
+int vz_init_wide_kernels();
+extern int g_wide_mode;
 int vz_linear_check_common(const LinearArgs& a);
 bool vz_gemv_ok(const LinearArgs& a);
 bool vz_skinny_ok(const LinearArgs& a);      // 2..16 rows: MFMA weight stream (gemm_skinny.hip)
