@@ -54,7 +54,7 @@ static LinearArgs mk_linear(const void* A, int lda, const void* W, int ldw, void
 }
 
 // vz_tune_set(14, rows): from this many rows on a decode step's linears run on the 128^2 tile GEMM (65 = never)
-static int g_decode_tile_rows = 25;      // measured cross-over (profiles/r02_rows.txt): the tile route costs ~5.2 ms per step from 25 to 48 rows, the MFMA weight stream 5.25 at 24 and 5.79 at 32
+static int g_decode_tile_rows = 29;      // measured cross-over on the tiled weight copies (profiles/r02_rows.txt): MFMA weight stream 4.42 ms per step at 25 rows, 4.74 at 32; tile route 4.56 / 4.64
 static int g_decode_sk_short = 8;      // vz_tune_set(15, v): split-K factor of the K = 4096 decode projections (QKV, O) on the tile-GEMM route
 static int vz_decode_splitk(int N, int K, int act) {
     // In situ (rocprofv3 of a 64-row step, profiles/r02_rows.txt) the 128^2 kernel is bound by the bytes its workgroups keep in flight

@@ -638,7 +638,7 @@ int vz_launch_skinny(const LinearArgs& a, hipStream_t s) {
 #undef VZ_WIDE_MH
 #undef VZ_WIDE
     }
-    if (g_skinny_mode != 2 && skinny_persist_ok(a) && (a.M > 4 || g_skinny_mode == 3)) {      // knob 9: 2 = never, 3 = also for 2..4 rows
+    if (g_skinny_mode != 2 && skinny_persist_ok(a) && (a.M >= 3 || g_skinny_mode == 3)) {      // knob 9: 2 = never (3..4 rows joined in round 2: 3.59 / 3.61 vs 3.69 / 3.68 ms per step on the tiled weights)
         const size_t pl = skinny_persist_lds(a);
         if (p.W8) return sw ? launch_persist<true, true>(p, blocks, pl, s) : launch_persist<false, true>(p, blocks, pl, s);
         return sw ? launch_persist<true, false>(p, blocks, pl, s) : launch_persist<false, false>(p, blocks, pl, s);
