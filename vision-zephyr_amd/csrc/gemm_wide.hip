@@ -78,8 +78,10 @@ __global__ __launch_bounds__(NWV * 64) void wide_tiled_kernel(WideParams p) {
     const int step0 = sp * p.cps * CH;
     const bf16_t* wa = p.Wt + ((size_t)G * S + step0) * 1024 + lane * 8;
 
-    // ---- weight ring: slot u holds step u of the current chunk, refilled with the next chunk's step u once its MFMAs are issued
-    //      (16 KiB per wave in flight; a second bank - 32 KiB - and non-temporal loads both measured no faster) ----
+    // ---- weight ring: slot u holds step u of the current chunk (16 KiB per wave in flight), refilled with the next chunk's step u right
+    //      after its MFMAs.  A second bank (32 KiB per wave, counted waits that leave a whole chunk in flight) measured SLOWER - 56.8
+    //      against 51.1 us on gate|up - as did non-temporal loads; see profiles/r02_rows.txt. ----
+    const int last = p.cps - 1;
     u32x4 qa[CH][2];
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
@@ -108,14 +110,18 @@ __global__ __launch_bounds__(NWV * 64) void wide_tiled_kernel(WideParams p) {
 #pragma unroll
     for (int h = 0; h < MH; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // The loop body is branch-free and order-pinned on purpose: hipcc counts its vmcnt waits exactly only while every load of the ring
+    // is issued unconditionally (with the refills behind `if (more)` it drained the queue - the fresh L2 loads of the next chunk's
+    // activations included - at the head of every chunk), and left alone its scheduler sinks every load of an iteration below the last
+    // MFMA (wait for everything, compute, then load).  The last chunk re-requests its own steps / activations (L2 hits, never used).
     int buf = 0;
     for (int c = 0; c < p.cps; ++c) {
-        const bool more = c + 1 < p.cps;
-        if (more) {
+        const int cn = c < last ? c + 1 : c;
 #pragma unroll
-            for (int i = 0; i < XL; ++i) xr[i] = *(const u32x4*)(xsrc[i] + (size_t)(c + 1) * CH * 64);
-        }
+        for (int i = 0; i < XL; ++i) xr[i] = *(const u32x4*)(xsrc[i] + (size_t)cn * CH * 64);
         const char* xs = smem + (size_t)buf * QN * 1024 + lane * 16;
+        const bf16_t* wnext = wa + (size_t)cn * CH * 1024;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
 #pragma unroll
@@ -125,17 +131,14 @@ __global__ __launch_bounds__(NWV * 64) void wide_tiled_kernel(WideParams p) {
                 acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qa[u][0]), as_bf16x8(b0), acc[h], 0, 0, 0);
                 acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qa[u][1]), as_bf16x8(b1), acc[h], 0, 0, 0);
             }
-            if (more) {
-                const bf16_t* wn = wa + (size_t)((c + 1) * CH + u) * 1024;
-                qa[u][0] = *(const u32x4*)wn;
-                qa[u][1] = *(const u32x4*)(wn + 512);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            qa[u][0] = *(const u32x4*)(wnext + (size_t)u * 1024);
+            qa[u][1] = *(const u32x4*)(wnext + (size_t)u * 1024 + 512);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) {
-            char* xd = smem + (size_t)(buf ^ 1) * QN * 1024;
+        char* xd = smem + (size_t)(buf ^ 1) * QN * 1024;
 #pragma unroll
-            for (int i = 0; i < XL; ++i) *(u32x4*)(xd + ((size_t)(wave + NWV * i) * 64 + lane) * 16) = xr[i];
-        }
+        for (int i = 0; i < XL; ++i) *(u32x4*)(xd + ((size_t)(wave + NWV * i) * 64 + lane) * 16) = xr[i];
         __syncthreads();           // chunk c + 1 is staged; everybody is done reading chunk c
         buf ^= 1;
     }
