@@ -20,7 +20,16 @@ def short(n):
 
 
 starts = [i for i, r in enumerate(rows) if "im2col" in r[2]]
-i0 = starts[-2] if len(starts) >= 2 and "--last" not in sys.argv else starts[-1]   # last TIMED step (the profiling replay follows it)
+# the last TIMED step = the last request whose decode phase is a full greedy generate (>= 100 argmax tails): the legs bench.py runs
+# after the timed region (roofline replays, the 16-token parity request, the sampled streamer path) do not qualify
+i0 = None
+for k in range(len(starts) - 1, -1, -1):
+    end = starts[k + 1] if k + 1 < len(starts) else len(rows)
+    if sum(1 for r in rows[starts[k]:end] if "argmax" in r[2]) >= 100:
+        i0 = starts[k]
+        break
+if i0 is None:
+    sys.exit("no full greedy request (im2col .. >= 100 argmax launches) in this trace")
 first_arg = next(i for i in range(i0, len(rows)) if "argmax" in rows[i][2])
 nxt = next((i for i in starts if i > i0), len(rows))
 for title, a, b in (("image->first-token", i0, first_arg + 1), ("decode", first_arg + 1, nxt)):

@@ -5,7 +5,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_A
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_BUSY_CYCLES SQ_WAVES"; do
   rm -rf /tmp/pmc_attn
-  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "flash_attn2_kernel<128" -d /tmp/pmc_attn -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/bench_kernels.py attn > /tmp/pmc_attn.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "flash_attn2_kernel<128, false, true>" -d /tmp/pmc_attn -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/bench_kernels.py attn > /tmp/pmc_attn.log 2>&1
   python3 - <<P
 import csv, glob, collections
 f = glob.glob("/tmp/pmc_attn/**/p_counter_collection.csv", recursive=True)

@@ -4,5 +4,5 @@
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_bench
 rocprofv3 --kernel-trace -d /tmp/prof_bench -o b --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp8-leg --steps 1 --warmup 1 "$@" > /tmp/bench_prof.log 2>&1
-tail -1 /tmp/bench_prof.log | cut -c1-300
+grep "^{" /tmp/bench_prof.log | tail -1 | cut -c1-300
 python3 $GRAFT_REPO_ROOT/tools/analyze_trace.py $(find /tmp/prof_bench -name "b_kernel_trace.csv") 
