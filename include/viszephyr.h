@@ -91,6 +91,11 @@ int vz_op_linear_impl(int impl, const void* d_A, int lda, const void* d_W, int l
                       int M, int N, int K, const float* d_bias, const void* d_residual, int ldr,
                       int act, int out_fp32, vz_stream stream);
 
+/* Causal-LM loss of forward(labels=...) (ref:vis_zephyr/model/language_model/vis_zephyr.py:51-98 hands labels to MistralForCausalLM.forward; hf:loss/loss_utils.py ForCausalLMLoss):
+ * fp32 logits [B, S, V], int32 labels [B, S] (-100 = ignored), row (b, s) scored against labels[b][s + 1], mean over the valid targets.
+ * d_loss_rows: B * S floats of scratch; d_out[0] = loss (NaN when no target is valid, as torch's mean), d_out[1] = number of valid targets. */
+int vz_op_causal_lm_loss(const float* d_logits, int B, int S, int V, const int* d_labels, float* d_loss_rows, float* d_out, vz_stream stream);
+
 /* y = LayerNorm(x) (torch.nn.LayerNorm; CLIP hf:...modeling_clip.py:353-384, Q-Former builder.py:14-27,68-70) */
 int vz_op_layernorm(const void* d_x, int ldx, void* d_y, int ldy, const float* d_w, const float* d_b,
                     int rows, int cols, float eps, vz_stream stream);

@@ -784,3 +784,30 @@ def test_stage1_shaped_batch_forward(env):
     ref = torch.nn.functional.cross_entropy(out.logits[:, :-1].reshape(-1, cfg.vocab), lab[:, 1:].reshape(-1), ignore_index=-100)
     assert abs(float(out.loss) - float(ref)) <= 1e-5 * abs(float(ref))
     assert int((lab != -100).sum()) == sum(l - 2 for l in lens)
+
+
+def test_forward_loss_on_device_and_cache_continuation(env):
+    """a2: the loss of forward(labels=...) is computed by the HIP cross-entropy (hf ForCausalLMLoss: shift, ignore -100, mean over the valid
+    targets) and equals torch's on the returned logits; forward(new ids, past_key_values=<handle>) continues on the engine's cache - its
+    logits equal the full forward's at those positions (two bf16 evaluation orders), a stale handle is refused."""
+    cfg, model, synth = env["cfg"], env["model"], env["synth"]
+    n = 37
+    ids = synth.synth_ids(n + 3, cfg.vocab, image_pos=-1, seed=77).unsqueeze(0).cuda()
+    labels = ids.clone()
+    labels[0, :5] = -100
+    labels[0, 20] = -100
+    full = model(input_ids=ids, labels=labels)
+    ref = torch.nn.functional.cross_entropy(full.logits[:, :-1].reshape(-1, cfg.vocab).float(), labels[:, 1:].reshape(-1), ignore_index=-100)
+    assert abs(float(full.loss) - float(ref)) <= 2e-5 * abs(float(ref)), (float(full.loss), float(ref))
+    none = model(input_ids=ids, labels=torch.full_like(ids, -100))
+    assert torch.isnan(none.loss)
+    head = model(input_ids=ids[:, :n])
+    stale = head.past_key_values
+    step = model(input_ids=ids[:, n:n + 2], past_key_values=head.past_key_values)
+    assert step.logits.shape == (1, 2, cfg.vocab) and step.past_key_values.lengths == [n + 2]
+    for t in range(2):
+        check_close(f"continued forward, new token {t}", step.logits[0, t], full.logits[0, n + t], 3e-2, 1e-2)
+    last = model(input_ids=ids[:, n + 2:n + 3], past_key_values=step.past_key_values)
+    check_close("continued forward, third token", last.logits[0, 0], full.logits[0, n + 2], 3e-2, 1e-2)
+    with pytest.raises(ValueError):
+        model(input_ids=ids[:, n:n + 1], past_key_values=stale)

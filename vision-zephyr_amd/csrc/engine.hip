@@ -114,6 +114,9 @@ extern "C" int vz_op_linear_impl(int impl, const void* A, int lda, const void* W
     vz_set_error("linear: unknown impl %d", impl);
     return VZ_ERR_ARG;
 }
+extern "C" int vz_op_causal_lm_loss(const float* logits, int B, int S, int V, const int* labels, float* loss_rows, float* out, vz_stream s) {
+    return vz_launch_causal_lm_loss(logits, B, S, V, labels, loss_rows, out, (hipStream_t)s);
+}
 extern "C" int vz_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* w, const float* b, int rows, int cols,
                                float eps, vz_stream s) {
     return vz_launch_layernorm((const bf16_t*)x, ldx, (bf16_t*)y, ldy, w, b, rows, cols, eps, (hipStream_t)s);

@@ -289,9 +289,9 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
     const long row = blockIdx.x;
     const int s = (int)(row % S), t = threadIdx.x;
     const int target = s + 1 < S ? labels[row + 1] : -100;
-    bf16_t* d = dlogits + row * ldd;
+    bf16_t* d = dlogits ? dlogits + row * ldd : nullptr;         // null: loss only (the forward path of the drop-in model)
     if (target < 0 || target >= V) {
-        for (int j = t; j < ldd; j += 256) d[j] = 0;
+        if (d) for (int j = t; j < ldd; j += 256) d[j] = 0;
         if (t == 0) loss_rows[row] = 0.f;
         return;
     }
@@ -307,8 +307,25 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
     for (int j = t; j < V; j += 256) sum += __expf(l[j] - m);
     sum = block_sum_256(sum, red);
     const float inv = inv_n / sum;
-    for (int j = t; j < ldd; j += 256) d[j] = j < V ? f32_to_bf16((__expf(l[j] - m) * inv) - (j == target ? inv_n : 0.f)) : (bf16_t)0;
+    if (d) for (int j = t; j < ldd; j += 256) d[j] = j < V ? f32_to_bf16((__expf(l[j] - m) * inv) - (j == target ? inv_n : 0.f)) : (bf16_t)0;
     if (t == 0) loss_rows[row] = (m + logf(sum)) - l[target];
+}
+
+// mean of loss_rows over the rows whose target is valid (label[b][s + 1] in [0, V)): one workgroup, thread t adds rows t, t + 256, ...
+// in order, then the 256 partials meet in a fixed order - out[0] = mean (NaN when nothing is valid, like torch), out[1] = valid count
+__global__ __launch_bounds__(256) void loss_mean_kernel(const float* __restrict__ loss_rows, const int* __restrict__ labels, long rows, int S, int V,
+                                                        float* __restrict__ out) {
+    __shared__ float red[4];
+    float sum = 0.f, cnt = 0.f;
+    for (long r = threadIdx.x; r < rows; r += 256) {
+        const int s = (int)(r % S);
+        const int target = s + 1 < S ? labels[r + 1] : -100;
+        if (target >= 0 && target < V) { sum += loss_rows[r]; cnt += 1.f; }
+    }
+    sum = block_sum_256(sum, red);
+    __syncthreads();
+    cnt = block_sum_256(cnt, red);
+    if (threadIdx.x == 0) { out[0] = sum / cnt; out[1] = cnt; }       // no valid target: 0 / 0 = NaN, as torch's mean over nothing
 }
 
 // out[c] += sum_r y[r][c]   (bias gradients).  Stage 1: workgroup (x, g) adds rows g, g + G, ... of its 256 columns (512-byte row
@@ -473,8 +490,19 @@ int vz_launch_rope_bwd_assemble(const bf16_t* dq, const float* dk, const float* 
 }
 int vz_launch_cross_entropy(const float* logits, int V, const int* labels, long rows, int S, float inv_n, float* loss_rows, bf16_t* dlogits, int ldd,
                             hipStream_t s) {
-    VZ_CHECK_ARG(logits && labels && loss_rows && dlogits && rows > 0 && ldd >= V, "cross_entropy: bad argument");
+    VZ_CHECK_ARG(logits && labels && loss_rows && rows > 0 && (!dlogits || ldd >= V), "cross_entropy: bad argument");
     hipLaunchKernelGGL(cross_entropy_kernel, dim3((int)rows), dim3(256), 0, s, logits, V, labels, S, inv_n, loss_rows, dlogits, ldd);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+// hf:loss/loss_utils.py ForCausalLMLoss on fp32 logits [B, S, V] and labels [B, S] (ignore_index -100, shift by one, mean over
+// the valid targets): d_loss_rows = B * S floats of scratch, d_out[0] = loss, d_out[1] = number of valid targets
+int vz_launch_causal_lm_loss(const float* logits, int B, int S, int V, const int* labels, float* loss_rows, float* out, hipStream_t s) {
+    VZ_CHECK_ARG(logits && labels && loss_rows && out && B > 0 && S > 0 && V > 0, "causal_lm_loss: bad argument");
+    const long rows = (long)B * S;
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3((int)rows), dim3(256), 0, s, logits, V, labels, S, 1.0f, loss_rows, (bf16_t*)nullptr, 0);
+    VZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(256), 0, s, (const float*)loss_rows, labels, rows, S, V, out);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }

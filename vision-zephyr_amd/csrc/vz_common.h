@@ -268,6 +268,7 @@ int vz_launch_swiglu_fwd(const bf16_t* gu, bf16_t* act, long rows, int I, hipStr
 int vz_launch_swiglu_bwd(const bf16_t* gu, const bf16_t* dact, bf16_t* dgu, long rows, int I, hipStream_t s);
 int vz_launch_rope_bwd_assemble(const bf16_t* dq, const float* dk, const float* dv, bf16_t* dqkv, const float* cosT, const float* sinT, const int* pos,
                                 int B, int S, int Hq, int Hkv, int D, int Sk_ld, hipStream_t s);
+int vz_launch_causal_lm_loss(const float* logits, int B, int S, int V, const int* labels, float* loss_rows, float* out, hipStream_t s);
 int vz_launch_cross_entropy(const float* logits, int V, const int* labels, long rows, int S, float inv_n, float* loss_rows, bf16_t* dlogits, int ldd,
                             hipStream_t s);
 int vz_colsum_groups(long rows);

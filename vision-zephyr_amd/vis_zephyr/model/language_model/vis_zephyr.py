@@ -93,8 +93,11 @@ class PastKeyValues:
     """The KV cache lives in the engine ([layer][k|v][slot][kv_head][pos][128] bf16); this handle records how
     many positions of each slot are filled."""
 
-    def __init__(self, lengths: Sequence[int]):
+    def __init__(self, lengths: Sequence[int], owner=None, epoch: int = 0, continuable: bool = False):
         self.lengths = list(lengths)
+        # which model's cache this describes and at which point of its history: the engine owns ONE cache, so a handle is live only
+        # until the next forward / generate (forward(past_key_values=...) checks it)
+        self.owner, self.epoch, self.continuable = owner, epoch, continuable
 
     def get_seq_length(self, layer_idx: int = 0):
         return max(self.lengths) if self.lengths else 0
@@ -122,6 +125,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
                                                  pad_token_id=getattr(config, "pad_token_id", None), top_k=50, top_p=1.0,
                                                  temperature=1.0)
         self._ring = None
+        self._kv_epoch = 0            # bumped by everything that rewrites the engine's KV cache: cache handles of earlier calls go stale
 
     # ---- construction helpers -------------------------------------------------------------------
     @classmethod
@@ -212,8 +216,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
                 output_hidden_states=None, images=None, images_size=None, return_dict=None, **kwargs):
         self._ensure_ready()
         if past_key_values is not None:
-            raise NotImplementedError("forward() with an external past_key_values: use generate(); the cache is "
-                                      "engine-owned")
+            return self._forward_continue(input_ids, attention_mask, position_ids, past_key_values, inputs_embeds, labels, images)
         if inputs_embeds is None:
             (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels) = \
                 self.prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
@@ -234,11 +237,42 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
             logits = torch.stack([torch.roll(logits[b], shifts[b], 0) for b in range(Bsz)])
         loss = None
         if labels is not None:
+            from vz_hip import binding as B
             lab = labels.to(logits.device)
-            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(),
-                                                     lab[:, 1:].reshape(-1), ignore_index=-100)
-        return SimpleNamespace(loss=loss, logits=logits, past_key_values=PastKeyValues(seqlens), hidden_states=None,
-                               attentions=None)
+            loss, _ = B.causal_lm_loss(logits.contiguous(), lab)      # hf ForCausalLMLoss on the device (shift, ignore -100, mean over valid)
+        self._kv_epoch += 1
+        return SimpleNamespace(loss=loss, logits=logits, past_key_values=PastKeyValues(seqlens, self, self._kv_epoch, shifts is None and Bsz <= mb),
+                               hidden_states=None, attentions=None)
+
+    def _forward_continue(self, input_ids, attention_mask, position_ids, past_key_values, inputs_embeds, labels, images):
+        """forward(input_ids [B, T], past_key_values=<handle of the previous forward>): HF's step API (hf:models/mistral/modeling_mistral.py
+        forward with a cache).  The KV cache is the engine's, so only the handle of the LATEST forward on this model is live; the new
+        tokens run as decode steps on top of it (teacher-forced), logits [B, T, V] and a handle T positions longer come back."""
+        if not isinstance(past_key_values, PastKeyValues) or past_key_values.owner is not self or past_key_values.epoch != self._kv_epoch:
+            raise ValueError("forward(past_key_values=...): this cache handle is stale - the engine owns ONE cache, and a later forward / "
+                             "generate call has overwritten it")
+        if not past_key_values.continuable:
+            raise NotImplementedError("forward(past_key_values=...) after a left-padded or chunked batch: re-run the prompt right-padded")
+        if images is not None or inputs_embeds is not None or labels is not None or input_ids is None:
+            raise NotImplementedError("forward(past_key_values=...) takes new input_ids only (the decode step embeds token ids on the device)")
+        ids = input_ids.to(self.device)
+        Bsz, T = ids.shape
+        if Bsz != len(past_key_values.lengths):
+            raise ValueError(f"forward(past_key_values=...): {Bsz} rows of new tokens for a cache of {len(past_key_values.lengths)} rows")
+        if attention_mask is not None and not bool(attention_mask[:, -T:].bool().all()):
+            raise NotImplementedError("forward(past_key_values=...): padded new tokens")
+        lens = list(past_key_values.lengths)
+        if max(lens) + T > self.engine.max_ctx:
+            raise ValueError(f"forward(past_key_values=...): {max(lens) + T} positions exceed max_ctx = {self.engine.max_ctx}")
+        out = torch.empty(Bsz, T, self.arch.vocab, dtype=torch.float32, device=self.device)
+        for t in range(T):
+            pos = [int(position_ids[b, t]) for b in range(Bsz)] if position_ids is not None else [l + t for l in lens]
+            self.engine.decode_begin(ids[:, t].to(torch.int32).contiguous(), pos, [l + t for l in lens])
+            _, lg = self.engine.decode_steps(1, return_logits=True)
+            out[:, t] = lg[0]
+        self._kv_epoch += 1
+        return SimpleNamespace(loss=None, logits=out, past_key_values=PastKeyValues([l + T for l in lens], self, self._kv_epoch, True),
+                               hidden_states=None, attentions=None)
 
     __call__ = forward
 
@@ -276,6 +310,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
     @torch.no_grad()
     def generate(self, input_ids: Optional[torch.Tensor] = None, images=None, images_size=None, **kwargs):
         self._ensure_ready()
+        self._kv_epoch += 1
         position_ids = kwargs.pop("position_ids", None)
         attention_mask = kwargs.pop("attention_mask", None)
         if "inputs_embeds" in kwargs:
@@ -390,6 +425,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         the next host sync (every `sync_every` steps), the other rows keep decoding.  Yields `(index, LongTensor[n_new])` in
         completion order; every sequence gets exactly the tokens `generate` gives it alone (rows are independent)."""
         from vz_hip import binding as B
+        self._kv_epoch += 1
         self._ensure_ready()
         eng = self.engine
         if eos_token_id is None:

@@ -47,6 +47,7 @@ SYMBOLS = {
     "vz_op_tile_weights": (_I, [_P, _I, _I, _I, _P, _P]),
     "vz_op_linear_tiled": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _F, _P]),
     "vz_op_linear_impl": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "vz_op_causal_lm_loss": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "vz_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _P]),
     "vz_op_rmsnorm": (_I, [_P, _I, _P, _I, _P, _I, _I, _F, _P]),
     "vz_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I] + [_L] * 12 + [_F, _I, _I, _I, _P, _P]),
@@ -236,6 +237,19 @@ def linear_fp8(x: torch.Tensor, w8: torch.Tensor, scale: torch.Tensor, bias=None
                                  ptr(bias), ptr(residual), 0 if residual is None else residual.stride(0), act, int(out_fp32),
                                  ptr(norm_w), float(norm_eps), stream_ptr(x.device)))
     return out
+
+
+def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor):
+    """(loss, valid target count) of fp32 logits [B, S, V] against labels [B, S] (-100 ignored), shifted by one, mean over valid targets."""
+    _need_cuda(logits)
+    assert logits.dtype == torch.float32 and logits.dim() == 3 and logits.is_contiguous()
+    Bn, S, V = logits.shape
+    lab = labels.to(logits.device, torch.int32).contiguous()
+    assert tuple(lab.shape) == (Bn, S)
+    rows = torch.empty(Bn * S, dtype=torch.float32, device=logits.device)
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    check(lib().vz_op_causal_lm_loss(ptr(logits), Bn, S, V, ptr(lab), ptr(rows), ptr(out), stream_ptr(logits.device)))
+    return out[0], out[1]
 
 
 def layernorm(x, w, b, eps):
