@@ -293,12 +293,13 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
         if (M > 16) t.norm_w = nullptr;   // 17..32 rows: the norm runs as its own kernel below
         if (!vz_gemv_ok(t) && !(g_skinny_mode && vz_skinny_ok(t))) { a.W8 = nullptr; a.wscale = nullptr; }
     }
-    if (klass_hint == 1 && M >= 17 && M <= 64 && a.Wt && !(W8 && ws)) {
+    if (klass_hint == 1 && M >= 17 && M <= 64 && a.Wt && (!(W8 && ws) || M >= std::max(g_decode_tile_rows, 33))) {      // (e4m3 engines: from where they leave the e4m3 stream anyway)
         // 17..64-row decode step on the tiled weight copy (gemm_wide.hip): weights straight to registers, the activations of a 512-k
         // chunk staged once per 128 weight rows - for the projections whose row blocks fill the chip without a K split (gate|up,
         // lm_head: measured 52.7 vs 62 us and 55 vs 91 us at 64 rows; the split shapes stay on the tile GEMM).  The RMSNorm runs
         // as its own launch.
         LinearArgs t = a;
+        t.W8 = nullptr; t.wscale = nullptr;          // (a weight_fp8 engine's bf16 tensors - and their tiled copies - hold the same dequantised values)
         if (norm_w) { t.A = e->d_xnorm; t.lda = K; t.norm_w = nullptr; }
         if (vz_wide_engine_ok(t)) {
             if (norm_w) {

@@ -357,7 +357,7 @@ class Engine:
     def finalize(self):
         if self.weight_fp8:
             self._quantize_decode_weights()
-        elif self.max_batch > 1:
+        if self.max_batch > (32 if self.weight_fp8 else 1):      # (an e4m3 engine streams e4m3 rows up to 32 rows; beyond, the bf16 routes)
             self._tile_decode_weights()
         for name, t in self.w.items():
             if name in self._registered:
