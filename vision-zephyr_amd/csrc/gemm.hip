@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const int nk_all = p.K / BK;
     const int k_lo = (int)((long)nk_all * split / p.splitk), k_hi = (int)((long)nk_all * (split + 1) / p.splitk);
     const int nk = k_hi - k_lo;
+    // A rows past M are never stored: their 32-row staging slices are not loaded at all (a 64-row decode step moves half the activation
+    // bytes per tile; tools/micro/stream_bench.hip: activation traffic through the vector-memory path costs the weight stream 20-34 %).
+    // The LDS rows keep whatever they held; the accumulators of those rows are dead.
+    const int a_slices = min(4, (p.M - bm * BM + 31) >> 5);
     auto stage = [&](int buf, int kt_rel) {
         const int kt = k_lo + kt_rel;
         char* la = smem + buf * BUF_BYTES + wave_chunk;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         const int kb = kt * (BK * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            glds16(ga[i] + kb, la + i * 4096);
+            if (i < a_slices) glds16(ga[i] + kb, la + i * 4096);
             glds16(gw[i] + kb, lw + i * 4096);
         }
     };

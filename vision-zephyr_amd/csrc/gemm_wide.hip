@@ -89,21 +89,28 @@ __global__ __launch_bounds__(NWV * 64) void wide_tiled_kernel(WideParams p) {
         qa[u][1] = *(const u32x4*)(wa + (size_t)u * 1024 + 512);
     }
 
-    // ---- activation staging: fragment q = (s * 2 + j) * MH + h of a chunk holds, for lane (m = fr, g), x[16 h + m][64 s + 16 g + 8 j .. + 7]
-    //      (rows past M repeat row M - 1: their outputs are never stored) ----
+    // ---- activation staging.  LDS image of a chunk: fragment q = (s * 2 + j) * MH + h (1 KiB) holds x[16 h + m][64 s + 16 g + 8 j .. + 7] of
+    //      lane (m, g) at 16-byte slot 16 g + (m ^ (2 s + j)) - the MFMA B operand of step s, half j, row block h is one ds_read_b128 per lane
+    //      over 1 KiB (conflict-free).  Each wave-instruction of the staging loads ONE row's 512 k (1 KiB contiguous: 8 whole lines; the
+    //      fragment-shaped load - 16 rows x 64 bytes - cost the weight stream another 10 % in tools/micro/stream_bench.hip) and scatters it:
+    //      lane l holds k = 8 l .. 8 l + 7, i.e. s = l >> 3, g = (l >> 1) & 3, j = l & 1; the XOR spreads a row's 64 pieces over all bank
+    //      groups (4-way conflicts on the write instead of 64-way).  Rows past M repeat row M - 1: their outputs are never stored. ----
     const bf16_t* xsrc[XL];
+    int xdst[XL];
+    {
+        const int sj = ((lane >> 3) << 1) | (lane & 1), gq = (lane >> 1) & 3;
 #pragma unroll
-    for (int i = 0; i < XL; ++i) {
-        const int q = wave + NWV * i;
-        const int h = q % MH, j = (q / MH) & 1, s = q / (2 * MH);
-        const int row = min(16 * h + fr, p.M - 1);
-        xsrc[i] = p.A + (size_t)row * p.lda + (size_t)(step0 + s) * 64 + 16 * g + 8 * j;
+        for (int i = 0; i < XL; ++i) {
+            const int row = wave + NWV * i;                      // 0 .. 16 MH - 1
+            xsrc[i] = p.A + (size_t)min(row, p.M - 1) * p.lda + (size_t)step0 * 64 + lane * 8;
+            xdst[i] = ((sj * MH + (row >> 4)) * 64 + gq * 16 + ((row & 15) ^ sj)) * 16;
+        }
     }
     u32x4 xr[XL];
 #pragma unroll
     for (int i = 0; i < XL; ++i) xr[i] = *(const u32x4*)xsrc[i];
 #pragma unroll
-    for (int i = 0; i < XL; ++i) *(u32x4*)(smem + ((size_t)(wave + NWV * i) * 64 + lane) * 16) = xr[i];
+    for (int i = 0; i < XL; ++i) *(u32x4*)(smem + xdst[i]) = xr[i];
     __syncthreads();
 
     f32x4 acc[MH];
@@ -119,15 +126,15 @@ __global__ __launch_bounds__(NWV * 64) void wide_tiled_kernel(WideParams p) {
         const int cn = c < last ? c + 1 : c;
 #pragma unroll
         for (int i = 0; i < XL; ++i) xr[i] = *(const u32x4*)(xsrc[i] + (size_t)cn * CH * 64);
-        const char* xs = smem + (size_t)buf * QN * 1024 + lane * 16;
+        const char* xs = smem + (size_t)buf * QN * 1024 + (lane & 48) * 16;
         const bf16_t* wnext = wa + (size_t)cn * CH * 1024;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
 #pragma unroll
             for (int h = 0; h < MH; ++h) {
-                const u32x4 b0 = *(const u32x4*)(xs + (size_t)((u * 2 + 0) * MH + h) * 1024);
-                const u32x4 b1 = *(const u32x4*)(xs + (size_t)((u * 2 + 1) * MH + h) * 1024);
+                const u32x4 b0 = *(const u32x4*)(xs + (size_t)((u * 2 + 0) * MH + h) * 1024 + ((fr ^ (u * 2 + 0)) << 4));
+                const u32x4 b1 = *(const u32x4*)(xs + (size_t)((u * 2 + 1) * MH + h) * 1024 + ((fr ^ (u * 2 + 1)) << 4));
                 acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qa[u][0]), as_bf16x8(b0), acc[h], 0, 0, 0);
                 acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(qa[u][1]), as_bf16x8(b1), acc[h], 0, 0, 0);
             }
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(NWV * 64) void wide_tiled_kernel(WideParams p) {
         }
         char* xd = smem + (size_t)(buf ^ 1) * QN * 1024;
 #pragma unroll
-        for (int i = 0; i < XL; ++i) *(u32x4*)(xd + ((size_t)(wave + NWV * i) * 64 + lane) * 16) = xr[i];
+        for (int i = 0; i < XL; ++i) *(u32x4*)(xd + xdst[i]) = xr[i];
         __syncthreads();           // chunk c + 1 is staged; everybody is done reading chunk c
         buf ^= 1;
     }
