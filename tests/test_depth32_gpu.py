@@ -178,3 +178,41 @@ def test_configs2_properties_at_32_layers(deep):
     ids_g = eng.decode_steps(4)
     assert torch.equal(ids_g, ids_e) and ids_g[0].tolist() == out[0, 1:5].tolist()
     eng.check_async()
+
+
+@pytest.mark.parametrize("Bn", [12, 40, 64])
+def test_batched_decode_step_equals_prefill_at_32_layers(deep, Bn):
+    """The batched decode routes at the headline depth (BASELINE configs[3] / [4] run 64 rows per GPU): a 12-row step (persistent MFMA weight
+    stream on the fragment-tiled copies), a 40- and a 64-row step (tile GEMM with split-K for QKV / O / down, gemm_wide.hip for gate|up and
+    lm_head) on a 32-layer engine - under teacher forcing every row's decode-step logits sit in the bf16 band around its own prefill logits
+    at that position (ragged prompt lengths, per-row positions and cache slots), and nothing is NaN."""
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    cfg, synth = deep["cfg"], deep["synth"]
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=32, num_attention_heads=cfg.n_heads,
+                         num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+                         sliding_window=cfg.sliding_window, eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    hf.mm_hidden_size = 5120
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=64, max_ctx=96, max_tiles=1, max_text=16)
+    eng = model.engine
+    lens = [24 + (5 * b) % 17 for b in range(Bn)]
+    Smax = max(lens) + 1
+    ids = torch.full((Bn, Smax), 2, dtype=torch.long)
+    for b in range(Bn):
+        ids[b, : lens[b] + 1] = synth.synth_ids(lens[b] + 1, cfg.vocab, image_pos=-1, seed=500 + b)
+    emb = eng.embed_tokens(ids)
+    full, _ = eng.prefill(emb, [l + 1 for l in lens], all_logits=True, last_logits=False)
+    eng.prefill(emb, lens, all_logits=False, last_logits=True)
+    eng.decode_begin(torch.tensor([int(ids[b, lens[b]]) for b in range(Bn)], dtype=torch.int32), lens, lens)
+    _, lg = eng.decode_steps(1, return_logits=True)
+    assert torch.isfinite(lg).all()
+    worst = 0.0
+    for b in range(Bn):
+        want = full[b, lens[b]].float().cpu()
+        worst = max(worst, _rel(lg[0, b].float().cpu().numpy(), want.numpy()))
+        check_close(f"depth32 B{Bn} row {b} decode step vs prefill row", lg[0, b], full[b, lens[b]], 8e-2, 1.6 * deep["e_a"] + 5e-4)
+    record(f"depth32 batched decode step vs prefill, {Bn} rows", worst_rel_l2=worst)
+    eng.check_async()
+    del model
+    torch.cuda.empty_cache()
