@@ -225,6 +225,25 @@ def fp8_leg_only(args):
                             "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach8 / HBM_PEAK_GBS, 4),
                             "traffic": None, "launches": n_l8, "avg_launch_ms": round(ms8 / max(1, n_l8), 5),
                             "algorithmic_bytes_per_launch": int(w_bytes8 / (4 * cfg.n_layers + 1))}}
+    # config 5's "fp8 MFMA weights": the same engine with its Zephyr prefill linears on the fp8 MFMA (e4m3 x e4m3, activations quantised
+    # per row on the device; gemm_fp8.hip) - first-token latency and the prefill linears' rate (the quantiser launches are counted in the latency)
+    e8.set_prefill_fp8(True)
+    step8()
+    r8m = [step8() for _ in range(args.steps)]
+    e8.prof_enable(True, B.K_GEMM)
+    e8.prefill(emb8, [S])
+    torch.cuda.synchronize()
+    n_lm, ms_m = e8.prof_read()
+    e8.prof_enable(False)
+    pre_flops8 = algorithmic_work(cfg, S, n_tiles)[1]
+    fp8_leg["fp8_mfma_prefill"] = {"image_to_first_token_ms": round(sum(a for a, _ in r8m) / args.steps * 1e3, 2),
+                                   "decode_tokens_per_s": round((n_new - 1) * args.steps / sum(b for _, b in r8m), 2),
+                                   "prefill_linears": {"achieved": round(pre_flops8 / (ms_m * 1e-3) / 1e12, 1), "unit": "TFLOP/s", "launches": n_lm,
+                                                       "total_ms": round(ms_m, 3), "peak_fp8_dense": 5000.0,
+                                                       "frac_of_fp8_peak": round(pre_flops8 / (ms_m * 1e-3) / 1e12 / 5000.0, 4)},
+                                   "what": "Zephyr prefill linears as e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (per-row power-of-two scales on both "
+                                           "operands); CLIP / Q-Former / lm_head / decode unchanged"}
+    e8.set_prefill_fp8(False)
     del model8, e8
     torch.cuda.empty_cache()
     print(json.dumps(fp8_leg), flush=True)

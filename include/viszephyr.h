@@ -73,6 +73,13 @@ int vz_op_linear(const void* d_A, int lda, const void* d_W, int ldw, void* d_C, 
 int vz_op_linear_fp8(const void* d_A, int lda, const void* d_W8, int ldw, const float* d_wscale, void* d_C, int ldc,
                      int M, int N, int K, const float* d_bias, const void* d_residual, int ldr, int act, int out_fp32,
                      const float* d_norm_w, float norm_eps, vz_stream stream);
+/* FP8 MFMA linear (config 5's prefill on a weight_fp8 engine): e4m3 activations x e4m3 weights on v_mfma_scale_f32_16x16x128_f8f6f4,
+ * one power-of-two scale per activation row and per weight row applied to the fp32 sum, then vz_op_linear's epilogues.
+ * vz_op_quant_rows_fp8 is the activation quantiser: scale[r] = 2^e with e the smallest integer such that max|x_row| <= 448 * 2^e,
+ * q = e4m3(x * 2^-e) round-to-nearest-even - the weights' quantiser (vz_hip/quant.py::quantize_rows), byte for byte.  K % 128 == 0. */
+int vz_op_quant_rows_fp8(const void* d_x, int ldx, void* d_q, int ldq, float* d_scale, int rows, int K, vz_stream stream);
+int vz_op_linear_fp8_mfma(const void* d_A8, int lda, const float* d_ascale, const void* d_W8, int ldw, const float* d_wscale, void* d_C, int ldc,
+                          int M, int N, int K, const float* d_bias, const void* d_residual, int ldr, int act, int out_fp32, vz_stream stream);
 /* x -> bf16(norm_w * x * rsqrt(mean(x^2) + eps)) fused into the staging of the weight-stream kernels (decode: QKV, gate-up,
  * lm_head; hf:models/mistral/modeling_mistral.py:182-199), then vz_op_linear's contract without bias.  1 <= M <= 16. */
 int vz_op_linear_rmsnorm(const void* d_A, int lda, const float* d_norm_w, float norm_eps, const void* d_W, int ldw, void* d_C, int ldc,
@@ -268,6 +275,9 @@ int vz_engine_async_error(vz_engine* e, int* err);
 int vz_op_async_error(vz_stream stream, int* err);
 /* TEST HOOK (tests/test_ops_gpu.py): overwrite the {arrive, ready} ticket pair of stream-K remainder tile `tile` on `stream`. */
 int vz_test_corrupt_streamk(vz_stream stream, int tile, int arrive, int ready);
+/* weight_fp8 engines: enable = 1 runs the Zephyr prefill linears as e4m3 x e4m3 on the scaled MFMA (inputs quantised per row by
+ * vz_op_quant_rows_fp8's kernel, weights = the registered e4m3 copies); 0 (default) = bf16 MFMA on the dequantised bf16 tensors */
+int vz_engine_prefill_fp8(vz_engine* e, int enable);
 /* forget a registered weight (e.g. the e4m3 copy of a bf16 tensor that has been rewritten) */
 int vz_engine_unset_weight(vz_engine* e, const char* name);
 /* Continuous batching.  vz_llm_prefill_rows: vz_llm_prefill into KV-cache rows row0 .. row0+B-1;

@@ -57,9 +57,17 @@ class Prec:
     model a checkpoint actually holds - separates weight rounding from the implementation's own activation rounding) and BF16
     (both: the bf16 band the HIP path is expected to sit in)."""
 
-    def __init__(self, bf16: bool = False, weights: Optional[bool] = None):
+    def __init__(self, bf16: bool = False, weights: Optional[bool] = None, act_fp8: bool = False):
         self.bf16 = bf16
         self.bf16_weights = bf16 if weights is None else weights
+        # fp8 MFMA prefill of the W8A16 engine (gemm_fp8.hip): the INPUT of every Zephyr prefill linear is rounded to e4m3 with one
+        # power-of-two scale per row (the weights' quantiser, fake_quantize_rows below); decode steps keep bf16 activations
+        self.act_fp8 = act_fp8
+
+    def q_in(self, x: torch.Tensor, prefill: bool) -> torch.Tensor:
+        if not (self.act_fp8 and prefill):
+            return x
+        return fake_quantize_rows(x.reshape(-1, x.shape[-1])).reshape(x.shape)
 
     def r(self, x: torch.Tensor) -> torch.Tensor:
         if not self.bf16:
@@ -81,6 +89,8 @@ class Prec:
 FP32 = Prec(False)
 BF16 = Prec(True)
 W16 = Prec(False, weights=True)
+FP32_FP8ACT = Prec(False, act_fp8=True)      # fp32 arithmetic on e4m3-quantised prefill activations (use with quantize_state_dict)
+BF16_FP8ACT = Prec(True, act_fp8=True)       # + bf16 rounding at the HIP path's store points
 
 
 def _lin(x, w, b, P: Prec):
@@ -418,7 +428,7 @@ def llm_forward(cfg, sd, inputs_embeds, attention_mask=None, position_ids=None, 
     newk, newv = [], []
     for i in range(cfg.n_layers):
         p = f"model.layers.{i}."
-        y = P.r(rmsnorm(x, sd[p + "input_layernorm.weight"], cfg.rms_eps))
+        y = P.q_in(P.r(rmsnorm(x, sd[p + "input_layernorm.weight"], cfg.rms_eps)), cache is None)
         q = P.r(_lin(y, sd[p + "self_attn.q_proj.weight"], None, P)).view(B, S, nh, hd)
         k = P.r(_lin(y, sd[p + "self_attn.k_proj.weight"], None, P)).view(B, S, nkv, hd)
         v = P.r(_lin(y, sd[p + "self_attn.v_proj.weight"], None, P)).view(B, S, nkv, hd)
@@ -429,12 +439,12 @@ def llm_forward(cfg, sd, inputs_embeds, attention_mask=None, position_ids=None, 
             v = torch.cat([cache.v[i], v], 1)
         newk.append(k)
         newv.append(v)
-        a = _attention(q, k, v, scale=hd ** -0.5, P=P, mask=keep).reshape(B, S, nh * hd)
+        a = P.q_in(_attention(q, k, v, scale=hd ** -0.5, P=P, mask=keep).reshape(B, S, nh * hd), cache is None)
         x = P.r(_lin(a, sd[p + "self_attn.o_proj.weight"], None, P) + x)
-        y = P.r(rmsnorm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_eps))
+        y = P.q_in(P.r(rmsnorm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_eps)), cache is None)
         g = _lin(y, sd[p + "mlp.gate_proj.weight"], None, P)
         u = _lin(y, sd[p + "mlp.up_proj.weight"], None, P)
-        a = P.r(F.silu(g) * u)
+        a = P.q_in(P.r(F.silu(g) * u), cache is None)
         x = P.r(_lin(a, sd[p + "mlp.down_proj.weight"], None, P) + x)
     hfin = P.r(rmsnorm(x, sd["model.norm.weight"], cfg.rms_eps))
     hl = hfin[:, -1:] if last_only else hfin

@@ -823,3 +823,41 @@ def test_wide_tiled_gemm(B, M, N, K, act):
     lo = 17 if M <= 32 else 33
     head = B.linear_tiled(x[:lo].contiguous(), w, wt, bias=bias, residual=res[:lo].contiguous(), act=act, out_fp32=True)
     assert torch.equal(head, out32[:lo])
+
+
+def test_quant_rows_fp8_equals_host_quantiser(B):
+    """the activation quantiser of the fp8 MFMA prefill = vz_hip.quant.quantize_rows (the weights' quantiser; the oracle's restatement is
+    checked against the same function in tests/test_quant_cpu.py): scales and e4m3 bytes equal, exact powers of two and the 448 boundary included."""
+    from vz_hip import quant
+    x = _rand((37, 4096), 3.0, 501).bfloat16()
+    x[0] = 0
+    x[1, 5] = 448.0
+    x[2, 7] = 449.0 * 4          # just past 1.75 * 2^k: the exponent steps up
+    x[3] = (torch.arange(4096, device="cuda") % 7 - 3).float().bfloat16() * 2.0 ** -20
+    x[4, 100] = 1.75 * 2.0 ** 3  # exactly on the boundary
+    q, sc = B.quant_rows_fp8(x)
+    q_ref, sc_ref = quant.quantize_rows(x)
+    assert torch.equal(sc, sc_ref.to(sc.device))
+    assert torch.equal(q, q_ref.to(q.device))
+
+
+@pytest.mark.parametrize("M,N,K,act", [(128, 4096, 4096, 0), (300, 6144, 4096, 0), (2048, 28672, 4096, 3), (257, 4096, 14336, 0), (64, 4000, 1024, 1)])
+def test_linear_fp8_mfma(B, M, N, K, act):
+    """e4m3 x e4m3 on the scaled-MFMA with per-row power-of-two scales: against the fp64 product of the DEQUANTISED operands (the
+    quantisation is exact data here, so only fp32 accumulation and the output rounding remain), through SwiGLU / bias / activation /
+    residual, bf16 and fp32 outputs, ragged M and N."""
+    from vz_hip import quant
+    x = _rand((M, K), 1.0, 510).bfloat16()
+    w = (_rand((N, K), 1.0, 511) * K ** -0.5).bfloat16()
+    x8, xs = B.quant_rows_fp8(x)
+    w8, ws = quant.quantize_rows(w)
+    xq = quant.dequantize_rows(x8, xs).bfloat16()       # exactly representable: 2^e * e4m3
+    wq = quant.dequantize_rows(w8, ws).bfloat16()
+    n_out = N // 2 if act == 3 else N
+    bias = None if act == 3 else _rand((N,), 0.1, 512)
+    res = _rand((M, n_out), 0.5, 513).bfloat16()
+    ref = _ref_linear(xq, wq, bias, res, act)
+    out32 = B.linear_fp8_mfma(x8, xs, w8.cuda(), ws.cuda(), bias=bias, residual=res, act=act, out_fp32=True)
+    check_close(f"fp8 mfma fp32 M{M} N{N} K{K} act{act}", out32, ref, 1e-4, 1e-4)
+    out = B.linear_fp8_mfma(x8, xs, w8.cuda(), ws.cuda(), bias=bias, residual=res, act=act)
+    check_close(f"fp8 mfma bf16 M{M} N{N} K{K} act{act}", out, ref, BF16_MAX, BF16_L2)

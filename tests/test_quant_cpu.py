@@ -36,3 +36,18 @@ def test_quantize_state_dict_touches_only_zephyr_linears():
     for k in sd:
         changed = not torch.equal(q[k], sd[k])
         assert changed == (k in ("model.layers.0.self_attn.q_proj.weight", "lm_head.weight")), k
+
+
+def test_oracle_fp8_activation_policy_cpu():
+    """the oracle's activation quantiser for the fp8 MFMA prefill: Prec(act_fp8=True).q_in is the weights' quantiser applied to the rows of the
+    linear's input in prefill, the identity in decode steps and under the other policies; every value it returns is 2^e * e4m3."""
+    import torch
+    from oracle import vz_oracle as O
+    from vz_hip import quant
+    torch.manual_seed(0)
+    x = torch.randn(2, 5, 64) * 3
+    q = O.FP32_FP8ACT.q_in(x, True)
+    assert torch.equal(q.reshape(-1, 64), quant.fake_quantize_rows(x.reshape(-1, 64)))
+    assert torch.equal(O.FP32_FP8ACT.q_in(x, False), x) and torch.equal(O.BF16.q_in(x, True), x)
+    q8, sc = quant.quantize_rows(q.reshape(-1, 64))
+    assert torch.equal(quant.dequantize_rows(q8, sc), q.reshape(-1, 64))      # a fixed point: already on the e4m3 grid

@@ -811,3 +811,53 @@ def test_forward_loss_on_device_and_cache_continuation(env):
     check_close("continued forward, third token", last.logits[0, 0], full.logits[0, n + 2], 3e-2, 1e-2)
     with pytest.raises(ValueError):
         model(input_ids=ids[:, n:n + 1], past_key_values=stale)
+
+
+def test_fp8_mfma_prefill_matches_quantized_oracle(env):
+    """Config 5's "fp8 MFMA weights": on a weight_fp8 engine with set_prefill_fp8() the Zephyr prefill linears run e4m3 x e4m3 on the scaled
+    MFMA - inputs quantised per row on the device, weights = the e4m3 copies.  Against the oracle that quantises IDENTICALLY (quantised
+    state dict + the same per-row activation quantiser in front of every prefill linear): logits inside the band the oracle's own
+    bf16-vs-fp32 distance defines (roundings may flip an e4m3 step, which that distance contains too); the cost of e4m3 activations against
+    the weight-only-quantised oracle is recorded and bounded by the oracle's own; decode steps (W8A16 stream, bf16 activations) continue from the fp8-prefilled
+    cache; switching the option off restores the bf16 prefill bit for bit."""
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    O, sd, synth, cfg = env["O"], env["sd"], env["synth"], env["cfg"]
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.n_layers,
+                         num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab,
+                         rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, sliding_window=cfg.sliding_window,
+                         eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    hf.mm_hidden_size = 5120
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=256, max_tiles=1, max_text=64, weight_fp8=True)
+    eng = model.engine
+    sdq = O.quantize_state_dict(sd)
+    ids = synth.synth_ids(150, cfg.vocab, image_pos=-1, seed=19)
+    emb = eng.embed_tokens(ids).unsqueeze(0)
+    bf16_prefill, _ = eng.prefill(emb, [150], all_logits=True, last_logits=False)
+    eng.set_prefill_fp8(True)
+    full, _ = eng.prefill(emb, [150], all_logits=True, last_logits=False)
+    lo_bf, _ = O.llm_forward(cfg, sdq, O.embed_tokens(sd, ids.unsqueeze(0), O.BF16), P=O.BF16_FP8ACT)
+    lo_32, _ = O.llm_forward(cfg, sdq, O.embed_tokens(sd, ids.unsqueeze(0), O.FP32), P=O.FP32_FP8ACT)
+    band("fp8 MFMA prefill logits", full, lo_bf, lo_32)
+    # what e4m3 activations cost on these (random, worst-case) weights: the distance to the weight-only-quantised model is of the size of
+    # the band itself - two identically quantising implementations already differ by it (a bf16-level difference flips e4m3 roundings)
+    lo_wonly, _ = O.llm_forward(cfg, sdq, O.embed_tokens(sd, ids.unsqueeze(0), O.FP32), P=O.FP32)
+    e_act = errs(full, lo_wonly)[1]
+    record("fp8 MFMA prefill: cost of e4m3 activations", hip_vs_weight_only_oracle=e_act, hip_vs_bf16_prefill_same_engine=errs(full, bf16_prefill)[1],
+           oracle_fp8act_vs_weight_only=errs(lo_32, lo_wonly)[1])
+    assert e_act <= 2.0 * errs(lo_32, lo_wonly)[1] + 5e-3
+    # decode continues from the fp8-prefilled cache (bf16 activations from here on): close to the prefill row of the next position
+    S0 = 120
+    _, last = eng.prefill(emb[:, :S0].contiguous(), [S0], all_logits=False, last_logits=True)
+    eng.decode_begin(ids[S0:S0 + 1].to(torch.int32), [S0], [S0])
+    _, lg = eng.decode_steps(1, return_logits=True)
+    e_or = errs(lo_bf, lo_32)[1]
+    check_close("decode step after an fp8 prefill vs the fp8 prefill row", lg[0, 0], full[0, S0], 0.25, 3.0 * e_or + 2e-2)
+    out = model.generate(input_ids=ids[:64].unsqueeze(0), do_sample=False, max_new_tokens=5, eos_token_id=None, pad_token_id=2)
+    assert out.shape == (1, 5)
+    eng.set_prefill_fp8(False)
+    again, _ = eng.prefill(emb, [150], all_logits=True, last_logits=False)
+    assert torch.equal(again, bf16_prefill)
+    del model
+    torch.cuda.empty_cache()

@@ -81,6 +81,16 @@ extern "C" int vz_op_linear_fp8(const void* A, int lda, const void* W8, int ldw,
     a.W8 = (const unsigned char*)W8; a.wscale = wscale; a.norm_w = norm_w; a.norm_eps = norm_eps;
     return vz_launch_linear(a, (hipStream_t)s);      // 1 row: GEMV; 2..16 rows: MFMA weight stream (gemm_skinny.hip)
 }
+extern "C" int vz_op_quant_rows_fp8(const void* x, int ldx, void* q, int ldq, float* scale, int rows, int K, vz_stream s) {
+    return vz_launch_quant_rows_fp8((const bf16_t*)x, ldx, (unsigned char*)q, ldq, scale, rows, K, (hipStream_t)s);
+}
+extern "C" int vz_op_linear_fp8_mfma(const void* A8, int lda, const float* ascale, const void* W8, int ldw, const float* wscale, void* C, int ldc,
+                                     int M, int N, int K, const float* bias, const void* residual, int ldr, int act, int out_fp32, vz_stream s) {
+    Fp8LinearArgs a;
+    a.A8 = (const unsigned char*)A8; a.lda = lda; a.ascale = ascale; a.W8 = (const unsigned char*)W8; a.ldw = ldw; a.wscale = wscale;
+    a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.bias = bias; a.residual = (const bf16_t*)residual; a.ldr = ldr; a.act = act; a.out_fp32 = out_fp32;
+    return vz_launch_gemm_fp8(a, (hipStream_t)s);
+}
 extern "C" int vz_op_linear_rmsnorm(const void* A, int lda, const float* norm_w, float norm_eps, const void* W, int ldw, void* C, int ldc,
                                     int M, int N, int K, const void* residual, int ldr, int act, int out_fp32, vz_stream s) {
     VZ_CHECK_ARG(norm_w && M >= 1 && M <= 16, "linear_rmsnorm: needs norm weights and 1 <= M <= 16 (the fused norm lives on the <= 16-row weight-stream kernels)");
@@ -195,6 +205,7 @@ struct vz_engine {
     // decode state (device)
     int* d_state = nullptr;  // [cur_ids[B] | pos[B] | slot[B] | len[B] | step]
     int dec_B = 0;
+    int prefill_fp8 = 0;         // vz_engine_prefill_fp8: the Zephyr prefill linears run e4m3 x e4m3 on the scaled MFMA (weight_fp8 engines)
     bool comm_graph_ok = true;   // RCCL collectives captured into the decode graph (cleared if a capture is refused -> eager steps)
     int dec_len_max = 0;         // host-side bound on the longest row's visible keys (grows by one per launched step)
     // host mirror of the device-side decode state, per row: keys visible to the NEXT step, its rotary position, and whether the
@@ -862,6 +873,7 @@ extern "C" int vz_llm_prefill_rows(vz_engine* e, int row0, const void* d_embeds,
         Carver m(nullptr, ~(size_t)0);
         m.take<bf16_t>((size_t)rows * H); m.take<bf16_t>((size_t)rows * H); m.take<bf16_t>((size_t)rows * QKV); m.take<bf16_t>((size_t)rows * A);
         m.take<bf16_t>((size_t)rows * A); m.take<bf16_t>((size_t)rows * I); m.take<int>(rows + B + 16); m.take<bf16_t>((size_t)B * H * 2);
+        m.take<unsigned char>((size_t)rows * std::max(std::max(H, A), I)); m.take<float>(rows);
         need = m.off + 256;
     }
     RC(ensure_arena(e, need));
@@ -874,6 +886,8 @@ extern "C" int vz_llm_prefill_rows(vz_engine* e, int row0, const void* d_embeds,
     bf16_t* act = m.take<bf16_t>((size_t)rows * I);
     int* d_ints = m.take<int>(rows + B + 16);   // slot[rows] | seqlens[B]
     bf16_t* ylast = m.take<bf16_t>((size_t)B * H * 2);
+    unsigned char* q8 = m.take<unsigned char>((size_t)rows * std::max(std::max(H, A), I));     // e4m3 copy of a linear's input rows + their scales
+    float* qs = m.take<float>(rows);                                                           // (fp8 MFMA prefill only)
     int* d_slot = d_ints;
     int* d_len = d_ints + rows;
     {
@@ -884,11 +898,29 @@ extern "C" int vz_llm_prefill_rows(vz_engine* e, int row0, const void* d_embeds,
         RC(upload_ints(e, h.data(), h.size(), d_ints, s));
     }
     int rc = VZ_OK;
+    // one Zephyr prefill linear: bf16 tile GEMM, or - weight_fp8 engine with vz_engine_prefill_fp8 on - the input rows quantised to e4m3
+    // (one power-of-two scale per row) and the product on the fp8 MFMA against the e4m3 weight copy (gemm_fp8.hip)
+    auto plin = [&](const bf16_t* Ain, const std::string& wname, int N, int K, void* Cout, int ldc, const bf16_t* res, int act) -> int {
+        const bf16_t* W = WB(wname + ".w", (long)N * K);
+        if (rc) return rc;
+        if (e->prefill_fp8 && tp_local(e) && vz_gemm_fp8_ok(rows, N, K, K, K)) {
+            const unsigned char* w8 = W8(wname + ".w8", (long)N * K);
+            const float* ws = WS(wname + ".ws", N);
+            if (rc) return rc;
+            { ProfScope ps(e, K_NORM, s); RC(vz_launch_quant_rows_fp8(Ain, K, q8, K, qs, rows, K, s)); }
+            Fp8LinearArgs f;
+            f.A8 = q8; f.lda = K; f.ascale = qs; f.W8 = w8; f.ldw = K; f.wscale = ws; f.C = Cout; f.ldc = ldc; f.M = rows; f.N = N; f.K = K;
+            f.bias = nullptr; f.residual = res; f.ldr = H; f.act = act; f.out_fp32 = 0;
+            ProfScope ps(e, K_GEMM, s);
+            return vz_launch_gemm_fp8(f, s);
+        }
+        return linear(e, 0, Ain, K, W, K, Cout, ldc, rows, N, K, nullptr, res, H, act, 0, s);
+    };
     { ProfScope ps(e, K_OTHER, s); RC(vz_launch_copy_rows((const bf16_t*)d_embeds, H, x, H, rows, H, s)); }
     for (int i = 0; i < c.n_layers; ++i) {
         const std::string p = "llm." + std::to_string(i) + ".";
         { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(x, H, y, H, WF(p + "in_norm", H), rows, H, c.rms_eps, s)); }
-        RC(linear(e, 0, y, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, rows, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s));
+        RC(plin(y, p + "qkv", QKV, H, qkv, QKV, nullptr, VZ_ACT_NONE));
         { ProfScope ps(e, K_OTHER, s); RC(vz_launch_rope_kv(qkv, QKV, q, kc_of(e, i) + row_off, vc_of(e, i) + row_off, e->cosT, e->sinT, d_pos, d_slot, B, S, Hq, Hkv, D, c.max_ctx, s)); }
         {
             ProfScope ps(e, K_ATTN, s);
@@ -902,11 +934,11 @@ extern "C" int vz_llm_prefill_rows(vz_engine* e, int row0, const void* d_embeds,
             a.causal = 1; a.q_pos0 = 0; a.window = c.sliding_window; a.kv_len = d_len;
             RC(vz_launch_attention(a, s));
         }
-        RC(linear(e, 0, att, A, WB(p + "o.w", (long)H * A), A, x, H, rows, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s));
+        RC(plin(att, p + "o", H, A, x, H, lead ? x : nullptr, VZ_ACT_NONE));
         RC(tp_allreduce_bf16(e, x, (size_t)rows * H, s));
         { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(x, H, y, H, WF(p + "post_norm", H), rows, H, c.rms_eps, s)); }
-        RC(linear(e, 0, y, H, WB(p + "gu.w", 2L * I * H), H, act, I, rows, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s));
-        RC(linear(e, 0, act, I, WB(p + "down.w", (long)I * H), I, x, H, rows, H, I, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s));
+        RC(plin(y, p + "gu", 2 * I, H, act, I, nullptr, VZ_ACT_SWIGLU));
+        RC(plin(act, p + "down", H, I, x, H, lead ? x : nullptr, VZ_ACT_NONE));
         RC(tp_allreduce_bf16(e, x, (size_t)rows * H, s));
         if (rc) return rc;
     }
@@ -1141,6 +1173,14 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
         e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena; e->dec_graph_nsplit = e->dec_nsplit; memcpy(e->dec_graph_samp, samp_key, sizeof(samp_key));
     }
     for (int i = 0; i < n; ++i) VZ_CHECK_HIP(hipGraphLaunch(e->dec_graph, s));
+    return VZ_OK;
+}
+
+// weight_fp8 engines: 1 = the Zephyr prefill linears quantise their input rows to e4m3 and run on the fp8 MFMA against the e4m3 weight
+// copies (config 5's "fp8 MFMA weights"; gemm_fp8.hip); 0 (default) = bf16 MFMA on the dequantised bf16 tensors.  Decode is untouched.
+extern "C" int vz_engine_prefill_fp8(vz_engine* e, int enable) {
+    VZ_CHECK_ARG(e && (!enable || e->c.weight_fp8), "prefill_fp8: needs an engine created with weight_fp8 = 1");
+    e->prefill_fp8 = enable ? 1 : 0;
     return VZ_OK;
 }
 

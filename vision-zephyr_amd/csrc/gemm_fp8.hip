@@ -1,0 +1,254 @@
+// FP8 MFMA prefill for the W8A16 engine (SURVEY config 5 "fp8 MFMA weights"; gfx950): C[M,N'] = epi(x8[M,K] . W8[N,K]^T * sx[m] * sw[n]).
+//
+//   * weights: the engine's e4m3 copies with ONE power-of-two scale per output row (vz_hip/quant.py) - unchanged;
+//   * activations: quant_rows_fp8_kernel gives every row of the bf16 input ONE power-of-two scale 2^e, e = the smallest integer with
+//     max|x_row| <= 448 * 2^e, and rounds x * 2^-e to OCP e4m3 (round-to-nearest-even) - the same quantiser as the weights'
+//     (vz_hip/quant.py::quantize_rows, which the oracle restates), so parity is against a reference that quantises identically;
+//   * the product runs on v_mfma_scale_f32_16x16x128_f8f6f4 with both block scales = 2^0 (an e4m3 x e4m3 product at twice the bf16
+//     rate per clock); the two row scales multiply the fp32 sum once, in the epilogue, like the W8A16 GEMV does.
+// Kernel = gemm.hip's 128 x 128 tile (4 waves x 64 x 64, 16-byte LDS-DMA into XOR-swizzled double buffers, 2 workgroups per CU) with a
+// K-tile of 128 BYTES = 128 k: the LDS image, the staging and the swizzle are byte-for-byte those of the bf16 kernel's 64-k tile; a
+// 16x16x128 fragment is 32 contiguous bytes of a row per lane (two ds_read_b128), 16 MFMAs per K-tile and wave instead of 64.
+// Both MFMA operands use the same lane -> k mapping (row / column = lane & 15, k bytes 32 (lane >> 4) .. + 31), which is all the
+// contraction needs.
+#include "vz_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+constexpr int BM = 128, BN = 128, BKB = 128;          // K-tile in bytes (= k)
+constexpr int TILE_BYTES = BM * BKB;                  // 16 KiB per operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;
+constexpr int FP8_LDS = 2 * BUF_BYTES;                // 64 KiB: 2 workgroups per CU
+
+struct Fp8Params {
+    const unsigned char* A8; const float* ascale; const unsigned char* W8; const float* wscale; void* C;
+    const float* bias; const bf16_t* residual;
+    int M, N, K, lda, ldw, ldc, ldr;
+    int act, out_fp32, tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const unsigned char* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == VZ_ACT_QUICK_GELU) return act_quick_gelu(v);
+    if (act == VZ_ACT_GELU_ERF) return act_gelu_erf(v);
+    return v;
+}
+
+// ---- per-row e4m3 quantisation of bf16 activations: one wave per row, two passes over the (L2-resident) row ----
+// e = x - 8 + (m > 1.75) for max|x| = m * 2^x, m in [1, 2): the smallest e with max|x| <= 448 * 2^e (448 = 1.75 * 2^8); no logarithm.
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int ldx, unsigned char* __restrict__ q, int ldq,
+                                                             float* __restrict__ scale, int rows, int K) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    float amax = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const u16x8 v = *(const u16x8*)(xr + k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(bf16_to_f32(v[j])));
+    }
+    amax = wave_max(amax);
+    int e = 0;
+    if (amax > 0.f) {
+        const unsigned bits = __float_as_uint(amax);
+        const int ex = (int)((bits >> 23) & 0xff) - 127;
+        const unsigned man = bits & 0x7fffffu;
+        e = ex - 8 + (man > 0x600000u ? 1 : 0);            // mantissa of 1.75 = 0x600000
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    }
+    const float inv = __uint_as_float((unsigned)(127 - e) << 23);     // 2^-e
+    if (lane == 0) scale[row] = __uint_as_float((unsigned)(127 + e) << 23);
+    unsigned char* qr = q + (size_t)row * ldq;
+    for (int k = lane * 8; k < K; k += 512) {
+        const u16x8 v = *(const u16x8*)(xr + k);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_to_f32(v[0]) * inv, bf16_to_f32(v[1]) * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_to_f32(v[2]) * inv, bf16_to_f32(v[3]) * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_to_f32(v[4]) * inv, bf16_to_f32(v[5]) * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_to_f32(v[6]) * inv, bf16_to_f32(v[7]) * inv, hi, true);
+        *(uint2*)(qr + k) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves, 64(m) x 64(n) each
+
+    // XCD-aware, bijective tile order (gemm.hip): blocks b and b+8 share an XCD; inside a run tiles walk M first
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int bn = tile / p.tiles_m, bm = tile - bn * p.tiles_m;
+
+    // ---- staging addresses: 1024 16-byte chunks per operand tile, 4 per thread ----
+    const unsigned char* ga[4];
+    const unsigned char* gw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = i * 256 + tid;
+        const int row = ch >> 3, c = ch & 7;
+        const int gc = c ^ (row & 7);  // swizzle on the source; the LDS image stays lane-linear
+        int arow = bm * BM + row; arow = arow < p.M ? arow : p.M - 1;
+        int wrow = bn * BN + row; wrow = wrow < p.N ? wrow : p.N - 1;
+        ga[i] = p.A8 + (size_t)arow * p.lda + gc * 16;
+        gw[i] = p.W8 + (size_t)wrow * p.ldw + gc * 16;
+    }
+    const int wave_chunk = wave * 64 * 16;
+
+    // ---- fragment read addresses (16x16x128: lane holds row lane&15, k bytes 32 g .. 32 g + 31 = chunks 2g, 2g+1) ----
+    const int frow = lane & 15, g = lane >> 4;
+    const int c0 = ((2 * g) ^ (frow & 7)) << 4, c1 = ((2 * g + 1) ^ (frow & 7)) << 4;
+    const int a_off = (wm * 64 + frow) * 128;
+    const int w_off = TILE_BYTES + (wn * 64 + frow) * 128;
+
+    f32x4 acc[4][4];  // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BKB;
+    const int a_slices = min(4, (p.M - bm * BM + 31) >> 5);       // activation rows past M are never stored: their slices are not loaded
+    auto stage = [&](int buf, int kt) {
+        char* la = smem + buf * BUF_BYTES + wave_chunk;
+        char* lw = la + TILE_BYTES;
+        const int kb = kt * BKB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < a_slices) glds16(ga[i] + kb, la + i * 4096);
+            glds16(gw[i] + kb, lw + i * 4096);
+        }
+    };
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    const int one = 0x7f7f7f7f;         // e8m0 127 = 2^0 in every byte: both block scales are 1
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* base = smem + cur * BUF_BYTES;
+        i32x8 af[4], wf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u32x4 a0 = *(const u32x4*)(base + a_off + t * 2048 + c0), a1 = *(const u32x4*)(base + a_off + t * 2048 + c1);
+            const u32x4 w0 = *(const u32x4*)(base + w_off + t * 2048 + c0), w1 = *(const u32x4*)(base + w_off + t * 2048 + c1);
+            af[t] = (i32x8){(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+            wf[t] = (i32x8){(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[mt], acc[nt][mt], 0, 0, 0, one, 0, one);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: acc[nt][mt][j] = sum for C[m = .. + mt*16 + (lane&15)][n = .. + nt*16 + 4*(lane>>4) + j] ----
+    const int m_base = bm * BM + wm * 64 + frow;
+    const int n_base = bn * BN + wn * 64 + g * 4;
+    const bool swiglu = p.act == VZ_ACT_SWIGLU;
+    const int n_out_total = swiglu ? p.N / 2 : p.N;
+    const bool vec_ok = (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m_base + mt * 16;
+        if (m >= p.M) continue;
+        const float sx = p.ascale[m];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            float v[4];
+            int n0;
+            if (swiglu) {
+                if (nt & 1) continue;
+                // weight rows are interleaved [16 gate | 16 up]: tile nt = gate, nt+1 = up, same lane slots
+                const int ng = n_base + nt * 16;                         // gate rows ng .. ng+3, up rows ng+16 ..
+                n0 = ((bn * BN + wn * 64) >> 1) + (nt >> 1) * 16 + g * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gt = acc[nt][mt][j] * (sx * p.wscale[ng + j]);
+                    const float up = acc[nt + 1][mt][j] * (sx * p.wscale[ng + 16 + j]);
+                    v[j] = act_silu(gt) * up;
+                }
+            } else {
+                n0 = n_base + nt * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = n0 + j < p.N ? acc[nt][mt][j] * (sx * p.wscale[n0 + j]) : 0.f;
+                    if (p.bias && n0 + j < p.N) t += p.bias[n0 + j];
+                    v[j] = apply_act(t, p.act);
+                }
+            }
+            if (n0 >= n_out_total) continue;
+            if (vec_ok && n0 + 3 < n_out_total) {
+                if (p.residual) {
+                    const u16x4 rr = *(const u16x4*)(p.residual + (size_t)m * p.ldr + n0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += bf16_to_f32(rr[j]);
+                }
+                if (p.out_fp32) {
+                    *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n0) = (f32x4){v[0], v[1], v[2], v[3]};
+                } else {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n0) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n0 + j >= n_out_total) break;
+                    float t = v[j];
+                    if (p.residual) t += bf16_to_f32(p.residual[(size_t)m * p.ldr + n0 + j]);
+                    if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + n0 + j] = t;
+                    else ((bf16_t*)p.C)[(size_t)m * p.ldc + n0 + j] = f32_to_bf16(t);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int vz_launch_quant_rows_fp8(const bf16_t* x, int ldx, unsigned char* q, int ldq, float* scale, int rows, int K, hipStream_t s) {
+    VZ_CHECK_ARG(x && q && scale && rows > 0 && K > 0 && (K & 7) == 0 && (ldx & 7) == 0 && (ldq & 7) == 0 && ldx >= K && ldq >= K,
+                 "quant_rows_fp8: K, ldx, ldq must be multiples of 8 (K=%d)", K);
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, q, ldq, scale, rows, K);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
+bool vz_gemm_fp8_ok(int M, int N, int K, int lda, int ldw) {
+    return M > 0 && N > 0 && K >= 128 && (K & 127) == 0 && (lda & 15) == 0 && (ldw & 15) == 0 && lda >= K && ldw >= K;
+}
+
+int vz_launch_gemm_fp8(const Fp8LinearArgs& a, hipStream_t s) {
+    VZ_CHECK_ARG(a.A8 && a.ascale && a.W8 && a.wscale && a.C, "gemm_fp8: null pointer");
+    VZ_CHECK_ARG(vz_gemm_fp8_ok(a.M, a.N, a.K, a.lda, a.ldw), "gemm_fp8: needs K %% 128 == 0 and 16-byte-aligned rows (M=%d N=%d K=%d)", a.M, a.N, a.K);
+    VZ_CHECK_ARG(((uintptr_t)a.A8 & 15) == 0 && ((uintptr_t)a.W8 & 15) == 0 && ((uintptr_t)a.C & 15) == 0, "gemm_fp8: pointers must be 16-byte aligned");
+    VZ_CHECK_ARG(a.act >= 0 && a.act <= 3 && (a.act != VZ_ACT_SWIGLU || ((a.N & 31) == 0 && !a.bias)), "gemm_fp8: bad activation / SwiGLU shape");
+    static bool attr = false;
+    if (!attr) {
+        VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FP8_LDS));
+        attr = true;
+    }
+    Fp8Params p;
+    p.A8 = a.A8; p.ascale = a.ascale; p.W8 = a.W8; p.wscale = a.wscale; p.C = a.C; p.bias = a.bias; p.residual = a.residual;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr; p.act = a.act; p.out_fp32 = a.out_fp32;
+    p.tiles_m = (a.M + BM - 1) / BM; p.tiles_n = (a.N + BN - 1) / BN;
+    vz_launch_timed(gemm_fp8_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), FP8_LDS, s, p);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}

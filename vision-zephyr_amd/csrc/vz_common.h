@@ -136,6 +136,16 @@ struct LinearArgs {
 };
 int vz_launch_gemm(const LinearArgs& a, hipStream_t s);
 int vz_launch_tile_weights(const bf16_t* W, int N, int K, int ldw, bf16_t* Wt, hipStream_t s);
+// gemm_fp8.hip: e4m3 x e4m3 MFMA GEMM (per-row power-of-two scales on both operands) + the activation quantiser
+struct Fp8LinearArgs {
+    const unsigned char* A8; int lda; const float* ascale;      // e4m3 activations [M, lda bytes] + 2^e per row
+    const unsigned char* W8; int ldw; const float* wscale;      // e4m3 weights [N, ldw bytes] + 2^e per row
+    void* C; int ldc; int M, N, K;
+    const float* bias; const bf16_t* residual; int ldr; int act; int out_fp32;
+};
+int vz_launch_quant_rows_fp8(const bf16_t* x, int ldx, unsigned char* q, int ldq, float* scale, int rows, int K, hipStream_t s);
+bool vz_gemm_fp8_ok(int M, int N, int K, int lda, int ldw);
+int vz_launch_gemm_fp8(const Fp8LinearArgs& a, hipStream_t s);
 // gemm_wide.hip: 17..64 rows on the tiled weight copy, activations staged once per 128 weight rows (needs a.Wt, no fused norm)
 bool vz_wide_ok(const LinearArgs& a);
 bool vz_wide_engine_ok(const LinearArgs& a);     // the shapes an engine's decode step routes there (no K split)

@@ -46,6 +46,9 @@ SYMBOLS = {
     "vz_op_linear": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "vz_op_tile_weights": (_I, [_P, _I, _I, _I, _P, _P]),
     "vz_op_linear_tiled": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _F, _P]),
+    "vz_engine_prefill_fp8": (_I, [_P, _I]),
+    "vz_op_quant_rows_fp8": (_I, [_P, _I, _P, _I, _P, _I, _I, _P]),
+    "vz_op_linear_fp8_mfma": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "vz_op_linear_impl": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "vz_op_causal_lm_loss": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "vz_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _P]),
@@ -250,6 +253,32 @@ def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor):
     out = torch.empty(2, dtype=torch.float32, device=logits.device)
     check(lib().vz_op_causal_lm_loss(ptr(logits), Bn, S, V, ptr(lab), ptr(rows), ptr(out), stream_ptr(logits.device)))
     return out[0], out[1]
+
+
+def quant_rows_fp8(x: torch.Tensor):
+    """bf16 [M, K] -> (e4m3 bytes uint8 [M, K], fp32 [M] power-of-two row scales): the device twin of vz_hip.quant.quantize_rows."""
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(lib().vz_op_quant_rows_fp8(ptr(x), x.stride(0), ptr(q), q.stride(0), ptr(sc), M, K, stream_ptr(x.device)))
+    return q, sc
+
+
+def linear_fp8_mfma(x8: torch.Tensor, xs: torch.Tensor, w8: torch.Tensor, ws: torch.Tensor, bias=None, residual=None, act: int = ACT_NONE,
+                    out_fp32=False) -> torch.Tensor:
+    """epi((x8 . w8^T) * xs[:, None] * ws[None, :]) on the fp8 MFMA; x8 / w8 uint8 e4m3 bytes, xs / ws fp32 row scales."""
+    _need_cuda(x8, xs, w8, ws, bias, residual)
+    assert x8.dtype == torch.uint8 and w8.dtype == torch.uint8 and xs.dtype == torch.float32 and ws.dtype == torch.float32
+    M, K = x8.shape
+    N = w8.shape[0]
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    out = torch.empty(M, n_out, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=x8.device)
+    check(lib().vz_op_linear_fp8_mfma(ptr(x8), x8.stride(0), ptr(xs), ptr(w8), w8.stride(0), ptr(ws), ptr(out), out.stride(0), M, N, K,
+                                      ptr(bias), ptr(residual), 0 if residual is None else residual.stride(0), act, int(out_fp32),
+                                      stream_ptr(x8.device)))
+    return out
 
 
 def layernorm(x, w, b, eps):

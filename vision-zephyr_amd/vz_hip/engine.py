@@ -61,6 +61,7 @@ class Engine:
             max_tiles=max_tiles, max_text=max_text, tp_size=tp_size, tp_rank=tp_rank,
             clip_keep_cls=int(cfg.clip_keep_cls), weight_fp8=int(weight_fp8))
         self.weight_fp8 = bool(weight_fp8)
+        self.prefill_fp8 = False
         h = C.c_void_p()
         B.check(self.lib.vz_engine_create(C.byref(c), C.byref(h)))
         self.h = h
@@ -70,6 +71,12 @@ class Engine:
         self._cos, self._sin = cos.to(self.device), sin.to(self.device)
         B.check(self.lib.vz_engine_set_rope(self.h, B.ptr(self._cos), B.ptr(self._sin), max_ctx))
         self.ready = False
+
+    def set_prefill_fp8(self, on: bool = True):
+        """weight_fp8 engines: run the Zephyr prefill linears on the fp8 MFMA (activations quantised to e4m3 per row on the device,
+        weights = the e4m3 copies the decode stream reads) instead of bf16 MFMA on the dequantised tensors.  Off by default."""
+        B.check(self.lib.vz_engine_prefill_fp8(self.h, int(bool(on))))
+        self.prefill_fp8 = bool(on)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
