@@ -77,6 +77,8 @@ int vz_op_linear_fp8(const void* d_A, int lda, const void* d_W8, int ldw, const 
  * one power-of-two scale per activation row and per weight row applied to the fp32 sum, then vz_op_linear's epilogues.
  * vz_op_quant_rows_fp8 is the activation quantiser: scale[r] = 2^e with e the smallest integer such that max|x_row| <= 448 * 2^e,
  * q = e4m3(x * 2^-e) round-to-nearest-even - the weights' quantiser (vz_hip/quant.py::quantize_rows), byte for byte.  K % 128 == 0. */
+/* RMSNorm + that quantiser in one launch (the bytes and scales of vz_op_rmsnorm followed by vz_op_quant_rows_fp8); cols <= 5120 */
+int vz_op_rmsnorm_quant_fp8(const void* d_x, int ldx, const float* d_w, float eps, void* d_q, int ldq, float* d_scale, int rows, int cols, vz_stream stream);
 int vz_op_quant_rows_fp8(const void* d_x, int ldx, void* d_q, int ldq, float* d_scale, int rows, int K, vz_stream stream);
 int vz_op_linear_fp8_mfma(const void* d_A8, int lda, const float* d_ascale, const void* d_W8, int ldw, const float* d_wscale, void* d_C, int ldc,
                           int M, int N, int K, const float* d_bias, const void* d_residual, int ldr, int act, int out_fp32, vz_stream stream);

@@ -839,6 +839,11 @@ def test_quant_rows_fp8_equals_host_quantiser(B):
     q_ref, sc_ref = quant.quantize_rows(x)
     assert torch.equal(sc, sc_ref.to(sc.device))
     assert torch.equal(q, q_ref.to(q.device))
+    # RMSNorm + quantiser in one launch = the two launches, byte for byte
+    nw = _rand((4096,), 0.2, 502) + 1.0
+    q2, sc2 = B.rmsnorm_quant_fp8(x, nw, 1e-5)
+    q3, sc3 = B.quant_rows_fp8(B.rmsnorm(x, nw, 1e-5))
+    assert torch.equal(sc2, sc3) and torch.equal(q2, q3)
 
 
 @pytest.mark.parametrize("M,N,K,act", [(128, 4096, 4096, 0), (300, 6144, 4096, 0), (2048, 28672, 4096, 3), (257, 4096, 14336, 0), (64, 4000, 1024, 1)])

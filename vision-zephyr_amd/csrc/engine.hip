@@ -81,6 +81,9 @@ extern "C" int vz_op_linear_fp8(const void* A, int lda, const void* W8, int ldw,
     a.W8 = (const unsigned char*)W8; a.wscale = wscale; a.norm_w = norm_w; a.norm_eps = norm_eps;
     return vz_launch_linear(a, (hipStream_t)s);      // 1 row: GEMV; 2..16 rows: MFMA weight stream (gemm_skinny.hip)
 }
+extern "C" int vz_op_rmsnorm_quant_fp8(const void* x, int ldx, const float* w, float eps, void* q, int ldq, float* scale, int rows, int cols, vz_stream s) {
+    return vz_launch_rmsnorm_quant_fp8((const bf16_t*)x, ldx, w, eps, (unsigned char*)q, ldq, scale, rows, cols, (hipStream_t)s);
+}
 extern "C" int vz_op_quant_rows_fp8(const void* x, int ldx, void* q, int ldq, float* scale, int rows, int K, vz_stream s) {
     return vz_launch_quant_rows_fp8((const bf16_t*)x, ldx, (unsigned char*)q, ldq, scale, rows, K, (hipStream_t)s);
 }
@@ -900,27 +903,33 @@ extern "C" int vz_llm_prefill_rows(vz_engine* e, int row0, const void* d_embeds,
     int rc = VZ_OK;
     // one Zephyr prefill linear: bf16 tile GEMM, or - weight_fp8 engine with vz_engine_prefill_fp8 on - the input rows quantised to e4m3
     // (one power-of-two scale per row) and the product on the fp8 MFMA against the e4m3 weight copy (gemm_fp8.hip)
-    auto plin = [&](const bf16_t* Ain, const std::string& wname, int N, int K, void* Cout, int ldc, const bf16_t* res, int act) -> int {
+    const bool f8 = e->prefill_fp8 && tp_local(e) && vz_gemm_fp8_ok(rows, QKV, H, H, H) && vz_gemm_fp8_ok(rows, H, I, I, I) && vz_gemm_fp8_ok(rows, H, A, A, A);
+    // norm_w != null: Ain is the residual stream and the RMSNorm belongs to this linear (fp8: norm + quantiser in one launch)
+    auto plin = [&](const bf16_t* Ain, const float* norm_w, const std::string& wname, int N, int K, void* Cout, int ldc, const bf16_t* res, int act) -> int {
         const bf16_t* W = WB(wname + ".w", (long)N * K);
         if (rc) return rc;
-        if (e->prefill_fp8 && tp_local(e) && vz_gemm_fp8_ok(rows, N, K, K, K)) {
+        if (f8) {
             const unsigned char* w8 = W8(wname + ".w8", (long)N * K);
             const float* ws = WS(wname + ".ws", N);
             if (rc) return rc;
-            { ProfScope ps(e, K_NORM, s); RC(vz_launch_quant_rows_fp8(Ain, K, q8, K, qs, rows, K, s)); }
+            {
+                ProfScope ps(e, K_NORM, s);
+                if (norm_w) RC(vz_launch_rmsnorm_quant_fp8(Ain, K, norm_w, c.rms_eps, q8, K, qs, rows, K, s));
+                else RC(vz_launch_quant_rows_fp8(Ain, K, q8, K, qs, rows, K, s));
+            }
             Fp8LinearArgs f;
             f.A8 = q8; f.lda = K; f.ascale = qs; f.W8 = w8; f.ldw = K; f.wscale = ws; f.C = Cout; f.ldc = ldc; f.M = rows; f.N = N; f.K = K;
             f.bias = nullptr; f.residual = res; f.ldr = H; f.act = act; f.out_fp32 = 0;
             ProfScope ps(e, K_GEMM, s);
             return vz_launch_gemm_fp8(f, s);
         }
-        return linear(e, 0, Ain, K, W, K, Cout, ldc, rows, N, K, nullptr, res, H, act, 0, s);
+        if (norm_w) { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(Ain, K, y, K, norm_w, rows, K, c.rms_eps, s)); }
+        return linear(e, 0, norm_w ? y : Ain, K, W, K, Cout, ldc, rows, N, K, nullptr, res, H, act, 0, s);
     };
     { ProfScope ps(e, K_OTHER, s); RC(vz_launch_copy_rows((const bf16_t*)d_embeds, H, x, H, rows, H, s)); }
     for (int i = 0; i < c.n_layers; ++i) {
         const std::string p = "llm." + std::to_string(i) + ".";
-        { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(x, H, y, H, WF(p + "in_norm", H), rows, H, c.rms_eps, s)); }
-        RC(plin(y, p + "qkv", QKV, H, qkv, QKV, nullptr, VZ_ACT_NONE));
+        RC(plin(x, WF(p + "in_norm", H), p + "qkv", QKV, H, qkv, QKV, nullptr, VZ_ACT_NONE));
         { ProfScope ps(e, K_OTHER, s); RC(vz_launch_rope_kv(qkv, QKV, q, kc_of(e, i) + row_off, vc_of(e, i) + row_off, e->cosT, e->sinT, d_pos, d_slot, B, S, Hq, Hkv, D, c.max_ctx, s)); }
         {
             ProfScope ps(e, K_ATTN, s);
@@ -934,11 +943,10 @@ extern "C" int vz_llm_prefill_rows(vz_engine* e, int row0, const void* d_embeds,
             a.causal = 1; a.q_pos0 = 0; a.window = c.sliding_window; a.kv_len = d_len;
             RC(vz_launch_attention(a, s));
         }
-        RC(plin(att, p + "o", H, A, x, H, lead ? x : nullptr, VZ_ACT_NONE));
+        RC(plin(att, nullptr, p + "o", H, A, x, H, lead ? x : nullptr, VZ_ACT_NONE));
         RC(tp_allreduce_bf16(e, x, (size_t)rows * H, s));
-        { ProfScope ps(e, K_NORM, s); RC(vz_launch_rmsnorm(x, H, y, H, WF(p + "post_norm", H), rows, H, c.rms_eps, s)); }
-        RC(plin(y, p + "gu", 2 * I, H, act, I, nullptr, VZ_ACT_SWIGLU));
-        RC(plin(act, p + "down", H, I, x, H, lead ? x : nullptr, VZ_ACT_NONE));
+        RC(plin(x, WF(p + "post_norm", H), p + "gu", 2 * I, H, act, I, nullptr, VZ_ACT_SWIGLU));
+        RC(plin(act, nullptr, p + "down", H, I, x, H, lead ? x : nullptr, VZ_ACT_NONE));
         RC(tp_allreduce_bf16(e, x, (size_t)rows * H, s));
         if (rc) return rc;
     }

@@ -78,6 +78,71 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
     }
 }
 
+// RMSNorm (hf:models/mistral/modeling_mistral.py:182-199) + the quantiser above in one pass: the normalised row is rounded to bf16 exactly
+// as norm_kernel stores it (w * (x * rstd)), then to e4m3 - the same bytes and scale as the two launches (tested), without the bf16 round trip
+// through HBM.  One wave per row, the row in registers (cols <= 5120).
+__global__ __launch_bounds__(256) void rmsnorm_quant_fp8_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ w, float eps,
+                                                                unsigned char* __restrict__ q, int ldq, float* __restrict__ scale, int rows, int cols) {
+    constexpr int MAXC = 10;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    const int nch = (cols + 511) >> 9;
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int k = c * 512 + lane * 8;
+        if (c < nch && k < cols) {
+            const u16x8 t = *(const u16x8*)(xr + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[c][j] = bf16_to_f32(t[j]); s += v[c][j] * v[c][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+        }
+    }
+    s = wave_sum(s);
+    const float rstd = rsqrtf(s / (float)cols + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int k = c * 512 + lane * 8;
+        if (c < nch && k < cols) {
+            const f32x4 w0 = *(const f32x4*)(w + k), w1 = *(const f32x4*)(w + k + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float wj = j < 4 ? w0[j] : w1[j - 4];
+                v[c][j] = bf16_to_f32(f32_to_bf16(wj * (v[c][j] * rstd)));
+                amax = fmaxf(amax, fabsf(v[c][j]));
+            }
+        }
+    }
+    amax = wave_max(amax);
+    int e = 0;
+    if (amax > 0.f) {
+        const unsigned bits = __float_as_uint(amax);
+        e = (int)((bits >> 23) & 0xff) - 127 - 8 + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    }
+    const float inv = __uint_as_float((unsigned)(127 - e) << 23);
+    if (lane == 0) scale[row] = __uint_as_float((unsigned)(127 + e) << 23);
+    unsigned char* qr = q + (size_t)row * ldq;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int k = c * 512 + lane * 8;
+        if (c < nch && k < cols) {
+            int lo = 0, hi = 0;
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] * inv, v[c][1] * inv, lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] * inv, v[c][3] * inv, lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][4] * inv, v[c][5] * inv, hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][6] * inv, v[c][7] * inv, hi, true);
+            *(uint2*)(qr + k) = make_uint2((unsigned)lo, (unsigned)hi);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -226,6 +291,15 @@ int vz_launch_quant_rows_fp8(const bf16_t* x, int ldx, unsigned char* q, int ldq
     VZ_CHECK_ARG(x && q && scale && rows > 0 && K > 0 && (K & 7) == 0 && (ldx & 7) == 0 && (ldq & 7) == 0 && ldx >= K && ldq >= K,
                  "quant_rows_fp8: K, ldx, ldq must be multiples of 8 (K=%d)", K);
     hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, q, ldq, scale, rows, K);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
+int vz_launch_rmsnorm_quant_fp8(const bf16_t* x, int ldx, const float* w, float eps, unsigned char* q, int ldq, float* scale, int rows, int cols,
+                                hipStream_t s) {
+    VZ_CHECK_ARG(x && w && q && scale && rows > 0 && (cols & 7) == 0 && cols <= 5120 && (ldx & 7) == 0 && (ldq & 7) == 0,
+                 "rmsnorm_quant_fp8: cols=%d must be a multiple of 8 and <= 5120", cols);
+    hipLaunchKernelGGL(rmsnorm_quant_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, w, eps, q, ldq, scale, rows, cols);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }

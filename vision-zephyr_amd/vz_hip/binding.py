@@ -47,6 +47,7 @@ SYMBOLS = {
     "vz_op_tile_weights": (_I, [_P, _I, _I, _I, _P, _P]),
     "vz_op_linear_tiled": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _F, _P]),
     "vz_engine_prefill_fp8": (_I, [_P, _I]),
+    "vz_op_rmsnorm_quant_fp8": (_I, [_P, _I, _P, _F, _P, _I, _P, _I, _I, _P]),
     "vz_op_quant_rows_fp8": (_I, [_P, _I, _P, _I, _P, _I, _I, _P]),
     "vz_op_linear_fp8_mfma": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "vz_op_linear_impl": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
@@ -263,6 +264,17 @@ def quant_rows_fp8(x: torch.Tensor):
     q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
     sc = torch.empty(M, dtype=torch.float32, device=x.device)
     check(lib().vz_op_quant_rows_fp8(ptr(x), x.stride(0), ptr(q), q.stride(0), ptr(sc), M, K, stream_ptr(x.device)))
+    return q, sc
+
+
+def rmsnorm_quant_fp8(x: torch.Tensor, w: torch.Tensor, eps: float):
+    """rmsnorm(x) rounded to bf16, then quant_rows_fp8 - in one launch; returns (e4m3 bytes [M, K], fp32 [M] scales)."""
+    _need_cuda(x, w)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(lib().vz_op_rmsnorm_quant_fp8(ptr(x), x.stride(0), ptr(w), float(eps), ptr(q), q.stride(0), ptr(sc), M, K, stream_ptr(x.device)))
     return q, sc
 
 
