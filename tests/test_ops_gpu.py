@@ -846,7 +846,8 @@ def test_quant_rows_fp8_equals_host_quantiser(B):
     assert torch.equal(sc2, sc3) and torch.equal(q2, q3)
 
 
-@pytest.mark.parametrize("M,N,K,act", [(128, 4096, 4096, 0), (300, 6144, 4096, 0), (2048, 28672, 4096, 3), (257, 4096, 14336, 0), (64, 4000, 1024, 1)])
+@pytest.mark.parametrize("M,N,K,act", [(128, 4096, 4096, 0), (300, 6144, 4096, 0), (2048, 28672, 4096, 3), (257, 4096, 14336, 0), (64, 4000, 1024, 1),
+                                       (2048, 4096, 14336, 0), (2048, 6144, 4096, 0)])
 def test_linear_fp8_mfma(B, M, N, K, act):
     """e4m3 x e4m3 on the scaled-MFMA with per-row power-of-two scales: against the fp64 product of the DEQUANTISED operands (the
     quantisation is exact data here, so only fp32 accumulation and the output rounding remain), through SwiGLU / bias / activation /
@@ -862,7 +863,13 @@ def test_linear_fp8_mfma(B, M, N, K, act):
     bias = None if act == 3 else _rand((N,), 0.1, 512)
     res = _rand((M, n_out), 0.5, 513).bfloat16()
     ref = _ref_linear(xq, wq, bias, res, act)
-    out32 = B.linear_fp8_mfma(x8, xs, w8.cuda(), ws.cuda(), bias=bias, residual=res, act=act, out_fp32=True)
-    check_close(f"fp8 mfma fp32 M{M} N{N} K{K} act{act}", out32, ref, 1e-4, 1e-4)
-    out = B.linear_fp8_mfma(x8, xs, w8.cuda(), ws.cuda(), bias=bias, residual=res, act=act)
-    check_close(f"fp8 mfma bf16 M{M} N{N} K{K} act{act}", out, ref, BF16_MAX, BF16_L2)
+    try:
+        for choice, what in ((1, "two-stage 128^2 kernel"), (2, "256^2 pipeline (gemm256.hip's ring, stream-K tail included)")):
+            B.check(B.lib().vz_tune_set(21, choice))
+            out32 = B.linear_fp8_mfma(x8, xs, w8.cuda(), ws.cuda(), bias=bias, residual=res, act=act, out_fp32=True)
+            check_close(f"fp8 mfma fp32 M{M} N{N} K{K} act{act} {what}", out32, ref, 1e-4, 1e-4)
+            out = B.linear_fp8_mfma(x8, xs, w8.cuda(), ws.cuda(), bias=bias, residual=res, act=act)
+            check_close(f"fp8 mfma bf16 M{M} N{N} K{K} act{act} {what}", out, ref, BF16_MAX, BF16_L2)
+    finally:
+        B.check(B.lib().vz_tune_set(21, 0))
+    assert B.op_async_error() == 0

@@ -1229,7 +1229,7 @@ extern "C" int vz_test_corrupt_streamk(vz_stream stream, int tile, int arrive, i
     return vz_gemm256_corrupt_tickets((hipStream_t)stream, tile, arrive, ready);
 }
 
-extern int g_gemm256_streamk, g_gemm256_skew, g_gemm256_stamps, g_gemm256_drain, g_attn_stamp_on;
+extern int g_gemm256_streamk, g_gemm256_skew, g_gemm256_stamps, g_gemm256_drain, g_attn_stamp_on, g_fp8_gemm_choice;
 int vz_gemm256_read_stamps(long long* host, int max_wgs, int* n_wgs);
 extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 0) { vz_set_gemv_variant(value); return VZ_OK; }
@@ -1244,6 +1244,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 11) { g_gemm256_drain = value; return VZ_OK; }
     if (knob == 14) { g_decode_tile_rows = value; return VZ_OK; }
     if (knob == 19) { g_wide_mode = value; return VZ_OK; }
+    if (knob == 21) { g_fp8_gemm_choice = value; return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }
     if (knob == 10) { if (value < 0 || value > 64) { vz_set_error("tune_set: decode attention splits must be 0..64"); return VZ_ERR_ARG; } g_attn_nsplit = value; return VZ_OK; }

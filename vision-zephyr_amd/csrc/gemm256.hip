@@ -60,6 +60,9 @@ struct Gemm256Params {
     float* ws; int* tickets;
     int* err;                // async error word: a bounded wait of the stream-K fix-up that expired raises VZ_ASYNC_STREAMK here
     long long* stamps;   // profiling only (vz_tune_set(6, 1)): s_memrealtime at phase boundaries, 16 per workgroup
+    // FP8 instantiation (gemm256_fp8_kernel): A / W point at e4m3 bytes, lda / ldw / K count bytes = k, a K-tile is 128 k; the
+    // fp32 sums are multiplied by ascale[m] * wscale[n] (one power-of-two scale per activation row / weight row) before the epilogue
+    const float* ascale; const float* wscale;
 };
 
 __device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
@@ -272,12 +275,34 @@ __device__ __forceinline__ int xcd_order(int bid, int nwg) {
     asm volatile("" ::: "memory");                          \
     __builtin_amdgcn_sched_barrier(0);
 
-__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
+// FP8 = false: bf16 operands, K-tile = 64 k, two k-steps of v_mfma_f32_16x16x32_bf16 per K-tile.  FP8 = true: e4m3 operands, K-tile = 128 k =
+// the SAME 128 bytes per row - ring, staging, swizzle, waits and barriers are byte-for-byte those of the bf16 kernel - and ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 (block scales 2^0) per accumulator and K-tile: the same matrix-pipe cycles per K-tile for twice the
+// FLOPs.  A lane's fragment is then 32 contiguous bytes of its row (chunks 2g, 2g+1) instead of chunks g and g+4.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+__device__ __forceinline__ i32x8_t cat8(bf16x8 lo, bf16x8 hi) {
+    const i32x4_t a = __builtin_bit_cast(i32x4_t, lo), b = __builtin_bit_cast(i32x4_t, hi);
+    return (i32x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+template <bool FP8>
+__device__ __forceinline__ f32x4 mma2(const bf16x8 (&w)[2], const bf16x8 (&a)[2], f32x4 c) {
+    if constexpr (FP8) {
+        return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat8(w[0], w[1]), cat8(a[0], a[1]), c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    } else {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], a[0], c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], a[1], c, 0, 0, 0);
+    }
+}
+
+template <bool FP8>
+__device__ __forceinline__ void gemm256_body(Gemm256Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY LDS object (a second one makes hipcc drain vmcnt)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;      // 2 x 4 waves, 128(m) x 64(n) each
     const int fr = lane & 15, g = lane >> 4;
-    const int nk = p.K >> 6;
+    const int nk = FP8 ? p.K >> 7 : p.K >> 6;
+    constexpr int ESZ = FP8 ? 1 : 2;
     const int wave_off = wave * 1024;
     const bool late = wm != 0;
 
@@ -299,7 +324,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
     }
 
     // ---- fragment read offsets ----
-    const int koff0 = (g ^ (lane & 7)) << 4;                     // k-step 0; k-step 1 = koff0 ^ 64
+    const int koff0 = FP8 ? ((2 * g) ^ (lane & 7)) << 4 : (g ^ (lane & 7)) << 4;     // bf16: k-step 0, k-step 1 = koff0 ^ 64; fp8: first / second half (koff0 ^ 16) of the fragment
+    constexpr int KS1 = FP8 ? 16 : 64;
     const int a_rd = (wm * 64 + fr) * 128;                       // + mt*2048 within A_h
     const int b_rd = (wn * 32 + fr) * 128;                       // + nt*2048 within B_h
     const bool swiglu = p.act == VZ_ACT_SWIGLU;
@@ -338,8 +364,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
                 arow = arow < p.M ? arow : p.M - 1;
                 int wrow = bn * 256 + (r >> 5) * 64 + h * 32 + (r & 31);      // LDS row r of B_h <-> wave col wn = r>>5
                 wrow = wrow < p.N ? wrow : p.N - 1;
-                src[h][j] = (const char*)p.A + (size_t)arow * p.lda * 2 + gc;
-                src[2 + h][j] = (const char*)p.W + (size_t)wrow * p.ldw * 2 + gc;
+                src[h][j] = (const char*)p.A + (size_t)arow * p.lda * ESZ + gc;
+                src[2 + h][j] = (const char*)p.W + (size_t)wrow * p.ldw * ESZ + gc;
             }
         }
         // region: 0 A_0, 1 A_1, 2 B_0, 3 B_1
@@ -382,17 +408,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    b0f[nt][ks] = *(const bf16x8*)(pb0 + b_rd + nt * 2048 + (koff0 ^ (ks * 64)));
-                    b1f[nt][ks] = *(const bf16x8*)(pb1 + b_rd + nt * 2048 + (koff0 ^ (ks * 64)));
+                    b0f[nt][ks] = *(const bf16x8*)(pb0 + b_rd + nt * 2048 + (koff0 ^ (ks * KS1)));
+                    b1f[nt][ks] = *(const bf16x8*)(pb1 + b_rd + nt * 2048 + (koff0 ^ (ks * KS1)));
                 }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const bf16x8*)(pa0 + a_rd + mt * 2048 + (koff0 ^ (ks * 64)));
+                for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const bf16x8*)(pa0 + a_rd + mt * 2048 + (koff0 ^ (ks * KS1)));
             stage_at(0, t + 2, st);                  // A_0, B_0 of tile t+2 into the slots B_1, A_1 of tile t-1 left
             stage_at(2, t + 2, ring_adv(st, 1));
             asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             PHASE_SYNC_BEGIN()
+            if constexpr (FP8) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        acc[0][0][nt][mt] = mma2<true>(b0f[nt], af[mt], acc[0][0][nt][mt]);
+                        acc[0][1][nt][mt] = mma2<true>(b1f[nt], af[mt], acc[0][1][nt][mt]);
+                    }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -402,18 +437,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
                         acc[0][0][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[nt][ks], af[mt][ks], acc[0][0][nt][mt], 0, 0, 0);
                         acc[0][1][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[nt][ks], af[mt][ks], acc[0][1][nt][mt], 0, 0, 0);
                     }
+            }
             PHASE_SYNC_END()
             // ================= phase beta: quadrants (1,0) and (1,1), B fragments still in registers =================
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const bf16x8*)(pa1 + a_rd + mt * 2048 + (koff0 ^ (ks * 64)));
+                for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const bf16x8*)(pa1 + a_rd + mt * 2048 + (koff0 ^ (ks * KS1)));
             stage_at(3, t + 2, ring_adv(st, 2));     // B_1, A_1 of tile t+2 into the slots A_0, B_0 of this tile (read in alpha)
             stage_at(1, t + 2, ring_adv(st, 3));
             asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             rd = ring_adv(rd, 4);
             st = ring_adv(st, 4);
             PHASE_SYNC_BEGIN()
+            if constexpr (FP8) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        acc[1][0][nt][mt] = mma2<true>(b0f[nt], af[mt], acc[1][0][nt][mt]);
+                        acc[1][1][nt][mt] = mma2<true>(b1f[nt], af[mt], acc[1][1][nt][mt]);
+                    }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -423,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
                         acc[1][0][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[nt][ks], af[mt][ks], acc[1][0][nt][mt], 0, 0, 0);
                         acc[1][1][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[nt][ks], af[mt][ks], acc[1][1][nt][mt], 0, 0, 0);
                     }
+            }
             PHASE_SYNC_END()
         }
         if (!late) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
@@ -510,6 +556,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
         }
 
         // ---- epilogue: acc[qm][qn][nt][mt][j] = C[m][n], m = .. + qm*64 + mt*16 + fr, n = .. + qn*32 + nt*16 + 4g + j ----
+        if constexpr (FP8) {
+            if (finish) {       // the two row scales (powers of two: exact) once, on the complete fp32 sums
+                const int m0 = bm * 256 + wm * 128 + fr, n0 = bn * 256 + wn * 64 + 4 * g;
+                float sx[2][4];
+#pragma unroll
+                for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) { const int m = m0 + qm * 64 + mt * 16; sx[qm][mt] = p.ascale[m < p.M ? m : p.M - 1]; }
+#pragma unroll
+                for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        float sw[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const int n = n0 + qn * 32 + nt * 16 + j; sw[j] = p.wscale[n < p.N ? n : p.N - 1]; }
+#pragma unroll
+                        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[qm][qn][nt][mt][j] *= sx[qm][mt] * sw[j];
+                    }
+            }
+        }
         if (finish) {
             const int m_base = bm * 256 + wm * 128 + fr, n_base = bn * 256 + wn * 64;
             const bool interior = bn * 256 + 256 <= p.N && vec_ok && (((uintptr_t)p.bias) & 15) == 0;
@@ -543,6 +613,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) {
         if (u < u_end) __syncthreads();     // next slice re-stages the ring from slot 0
     }
 }
+
+__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(Gemm256Params p) { gemm256_body<false>(p); }
+__global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm256Params p) { gemm256_body<true>(p); }
 
 long long* g_stamps;         // 16 stamps per workgroup of the last launch (profiling knob 6)
 int g_stamp_wgs;
@@ -587,6 +660,7 @@ int vz_init_gemm256_kernel() {
     static bool done = false;
     if (done) return VZ_OK;
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES));
     int dev = 0;
     VZ_CHECK_HIP(hipGetDevice(&dev));
     VZ_CHECK_HIP(hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -596,18 +670,11 @@ int vz_init_gemm256_kernel() {
     return VZ_OK;
 }
 
-int vz_launch_gemm256(const LinearArgs& a, hipStream_t s) {
-    int rc = vz_linear_check_common(a);
-    if (rc) return rc;
-    VZ_CHECK_ARG(!a.norm_w, "linear: fused RMSNorm prologue exists on the GEMV path only");
-    { int r = vz_init_gemm256_kernel(); if (r) return r; }
-    Gemm256Params p;
-    p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.residual = a.residual;
-    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr;
-    p.act = a.act; p.out_fp32 = a.out_fp32;
-    p.tiles_m = (a.M + 255) / 256;
-    p.tiles_n = (a.N + 255) / 256;
-    const int T = p.tiles_m * p.tiles_n, P = g_num_cu, nk = a.K >> 6;
+// tile plan + stream-K tail for a filled parameter block (nk = K-tiles of this element type), then the launch
+static int plan_and_launch(Gemm256Params& p, int nk, int* err_word, bool fp8, hipStream_t s) {
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    const int T = p.tiles_m * p.tiles_n, P = g_num_cu;
     p.n_full = T; p.n_rem = 0; p.sk_wgs = 0; p.units_per_wg = 1; p.sk_skew = 0;
     p.ws = nullptr; p.tickets = nullptr; p.err = nullptr;
     const int rem = T % P;
@@ -626,7 +693,7 @@ int vz_launch_gemm256(const LinearArgs& a, hipStream_t s) {
             if (st && (size_t)(wgs + rem) * TILE_FLOATS * sizeof(float) <= st->ws_bytes && 2 * rem <= st->n_tickets) {
                 p.n_full = T - rem; p.n_rem = rem; p.sk_wgs = (int)wgs; p.units_per_wg = U;
                 p.sk_skew = U >= 24 ? g_gemm256_skew : 0;
-                p.ws = st->ws; p.tickets = st->tickets; p.err = a.err ? a.err : st->err;
+                p.ws = st->ws; p.tickets = st->tickets; p.err = err_word ? err_word : st->err;
             }
         }
     }
@@ -635,9 +702,32 @@ int vz_launch_gemm256(const LinearArgs& a, hipStream_t s) {
         p.stamps = g_stamps; g_stamp_wgs = p.n_full + p.sk_wgs;
         VZ_CHECK_HIP(hipMemsetAsync(g_stamps, 0, (size_t)g_stamp_wgs * 16 * sizeof(long long), s));
     }
-    vz_launch_timed(gemm256_bf16_kernel, dim3(p.n_full + p.sk_wgs), dim3(512), RING_BYTES, s, p);
+    if (fp8) vz_launch_timed(gemm256_fp8_kernel, dim3(p.n_full + p.sk_wgs), dim3(512), RING_BYTES, s, p);
+    else vz_launch_timed(gemm256_bf16_kernel, dim3(p.n_full + p.sk_wgs), dim3(512), RING_BYTES, s, p);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
+}
+
+int vz_launch_gemm256(const LinearArgs& a, hipStream_t s) {
+    int rc = vz_linear_check_common(a);
+    if (rc) return rc;
+    VZ_CHECK_ARG(!a.norm_w, "linear: fused RMSNorm prologue exists on the GEMV path only");
+    { int r = vz_init_gemm256_kernel(); if (r) return r; }
+    Gemm256Params p;
+    p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.residual = a.residual;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr;
+    p.act = a.act; p.out_fp32 = a.out_fp32; p.ascale = nullptr; p.wscale = nullptr;
+    return plan_and_launch(p, a.K >> 6, a.err, false, s);
+}
+
+// e4m3 x e4m3 on the same 8-phase pipeline (gemm_fp8.hip dispatches here for grids that fill the chip): K % 128 == 0
+int vz_launch_gemm256_fp8(const Fp8LinearArgs& a, hipStream_t s) {
+    { int r = vz_init_gemm256_kernel(); if (r) return r; }
+    Gemm256Params p;
+    p.A = (const bf16_t*)a.A8; p.W = (const bf16_t*)a.W8; p.C = a.C; p.bias = a.bias; p.residual = a.residual;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.ldr = a.ldr;
+    p.act = a.act; p.out_fp32 = a.out_fp32; p.ascale = a.ascale; p.wscale = a.wscale;
+    return plan_and_launch(p, a.K >> 7, nullptr, true, s);
 }
 
 // profiling: copy the phase stamps of the last stamped 256^2 launch (16 int64 per workgroup) to the host

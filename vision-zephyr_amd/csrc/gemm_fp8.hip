@@ -287,6 +287,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Params p) {
 
 }  // namespace
 
+int g_fp8_gemm_choice = 0;      // vz_tune_set(21, v): 0 = by grid size, 1 = always the 128^2 kernel, 2 = always the 256^2 pipeline
+
 int vz_launch_quant_rows_fp8(const bf16_t* x, int ldx, unsigned char* q, int ldq, float* scale, int rows, int K, hipStream_t s) {
     VZ_CHECK_ARG(x && q && scale && rows > 0 && K > 0 && (K & 7) == 0 && (ldx & 7) == 0 && (ldq & 7) == 0 && ldx >= K && ldq >= K,
                  "quant_rows_fp8: K, ldx, ldq must be multiples of 8 (K=%d)", K);
@@ -313,6 +315,11 @@ int vz_launch_gemm_fp8(const Fp8LinearArgs& a, hipStream_t s) {
     VZ_CHECK_ARG(vz_gemm_fp8_ok(a.M, a.N, a.K, a.lda, a.ldw), "gemm_fp8: needs K %% 128 == 0 and 16-byte-aligned rows (M=%d N=%d K=%d)", a.M, a.N, a.K);
     VZ_CHECK_ARG(((uintptr_t)a.A8 & 15) == 0 && ((uintptr_t)a.W8 & 15) == 0 && ((uintptr_t)a.C & 15) == 0, "gemm_fp8: pointers must be 16-byte aligned");
     VZ_CHECK_ARG(a.act >= 0 && a.act <= 3 && (a.act != VZ_ACT_SWIGLU || ((a.N & 31) == 0 && !a.bias)), "gemm_fp8: bad activation / SwiGLU shape");
+    // grids that fill the chip with 256^2 tiles run on gemm256.hip's deep pipeline (same bytes per K-tile as its bf16 form, twice the FLOPs);
+    // knob 21 = 1 keeps everything on the two-stage 128^2 kernel below (A/B)
+    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    // measured at M = 2048 (tools/bench_fp8.py): QKV (192 tiles) 70.5 vs 99.9 us, gate|up (896) 291 vs 314; O (128 tiles) 65.4 vs 58.5, down (128) 130 vs 128
+    if (g_fp8_gemm_choice != 1 && (g_fp8_gemm_choice == 2 || t256 >= 160)) return vz_launch_gemm256_fp8(a, s);
     static bool attr = false;
     if (!attr) {
         VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FP8_LDS));

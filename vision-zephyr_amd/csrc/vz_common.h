@@ -147,6 +147,7 @@ int vz_launch_quant_rows_fp8(const bf16_t* x, int ldx, unsigned char* q, int ldq
 int vz_launch_rmsnorm_quant_fp8(const bf16_t* x, int ldx, const float* w, float eps, unsigned char* q, int ldq, float* scale, int rows, int cols, hipStream_t s);
 bool vz_gemm_fp8_ok(int M, int N, int K, int lda, int ldw);
 int vz_launch_gemm_fp8(const Fp8LinearArgs& a, hipStream_t s);
+int vz_launch_gemm256_fp8(const Fp8LinearArgs& a, hipStream_t s);      // gemm256.hip's pipeline on e4m3 operands
 // gemm_wide.hip: 17..64 rows on the tiled weight copy, activations staged once per 128 weight rows (needs a.Wt, no fused norm)
 bool vz_wide_ok(const LinearArgs& a);
 bool vz_wide_engine_ok(const LinearArgs& a);     // the shapes an engine's decode step routes there (no K split)
