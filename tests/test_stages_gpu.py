@@ -821,6 +821,7 @@ def test_fp8_mfma_prefill_matches_quantized_oracle(env):
     the weight-only-quantised oracle is recorded and bounded by the oracle's own; decode steps (W8A16 stream, bf16 activations) continue from the fp8-prefilled
     cache; switching the option off restores the bf16 prefill bit for bit."""
     from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    from vz_hip import binding as B
     O, sd, synth, cfg = env["O"], env["sd"], env["synth"], env["cfg"]
     hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.n_layers,
                          num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab,
@@ -836,6 +837,9 @@ def test_fp8_mfma_prefill_matches_quantized_oracle(env):
     emb = eng.embed_tokens(ids).unsqueeze(0)
     bf16_prefill, _ = eng.prefill(emb, [150], all_logits=True, last_logits=False)
     eng.set_prefill_fp8(True)
+    short, _ = eng.prefill(emb, [150], all_logits=True, last_logits=False)
+    assert torch.equal(short, bf16_prefill)            # below 768 prefill rows the option keeps the bf16 GEMMs (not worth the quantiser launches)
+    B.check(B.lib().vz_tune_set(22, 0))               # ... unless told otherwise: this test runs the fp8 path on 150 rows
     full, _ = eng.prefill(emb, [150], all_logits=True, last_logits=False)
     lo_bf, _ = O.llm_forward(cfg, sdq, O.embed_tokens(sd, ids.unsqueeze(0), O.BF16), P=O.BF16_FP8ACT)
     lo_32, _ = O.llm_forward(cfg, sdq, O.embed_tokens(sd, ids.unsqueeze(0), O.FP32), P=O.FP32_FP8ACT)
@@ -857,6 +861,7 @@ def test_fp8_mfma_prefill_matches_quantized_oracle(env):
     out = model.generate(input_ids=ids[:64].unsqueeze(0), do_sample=False, max_new_tokens=5, eos_token_id=None, pad_token_id=2)
     assert out.shape == (1, 5)
     eng.set_prefill_fp8(False)
+    B.check(B.lib().vz_tune_set(22, 768))
     again, _ = eng.prefill(emb, [150], all_logits=True, last_logits=False)
     assert torch.equal(again, bf16_prefill)
     del model

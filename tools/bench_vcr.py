@@ -3,7 +3,7 @@
 tokens - through device preprocessing -> CLIP / fusion / Q-Former -> batched greedy generation.  Prints items/s and decode
 tokens/s for batch sizes 1..64 (bf16 weights, or `fp8` for the W8A16 engine).
 
-    python tools/bench_vcr.py [fp8] [layers]"""
+    python tools/bench_vcr.py [fp8 | fp8mfma] [layers]"""
 import os
 import sys
 import time
@@ -17,7 +17,8 @@ import torch  # noqa: E402
 from vz_hip import synth  # noqa: E402
 from vz_hip.preprocess import AnyresPreprocessor  # noqa: E402
 
-FP8 = "fp8" in sys.argv[1:]
+FP8 = "fp8" in sys.argv[1:] or "fp8mfma" in sys.argv[1:]
+FP8_MFMA = "fp8mfma" in sys.argv[1:]        # W8A16 engine with its Zephyr prefill linears on the fp8 MFMA (Engine.set_prefill_fp8)
 layers = next((int(a) for a in sys.argv[1:] if a.isdigit()), 32)
 PINS = [[336, 672], [672, 336], [336, 1008], [1008, 336], [672, 672]]
 N_NEW, L_PROMPT, MAXB = 128, 200, 64
@@ -33,6 +34,8 @@ hf.mm_grid_pinpoints = str(PINS)
 hf.mm_hidden_size = 5120
 model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, device="cuda:0", max_batch=MAXB, max_ctx=L_PROMPT + 4 * 32 + N_NEW + 16,
                                             max_tiles=4 * MAXB, max_text=L_PROMPT + 8, weight_fp8=FP8)
+if FP8_MFMA:
+    model.engine.set_prefill_fp8(True)
 pre = AnyresPreprocessor("cuda:0")
 rng = np.random.default_rng(0)
 frames = [torch.from_numpy(rng.integers(0, 256, (804, 1920, 3), dtype=np.uint8)) for _ in range(MAXB)]     # host memory, as a loader hands them over
@@ -55,7 +58,7 @@ for B in (() if "stream" in sys.argv[1:] else (1, 4, 8, 16, 32, 64)):
     run()
     best = min((run() for _ in range(2)), key=sum)
     tot = sum(best)
-    print(f"{'fp8 ' if FP8 else ''}batch {B:2d}: {B / tot:6.2f} items/s  ({tot * 1e3:7.1f} ms per batch: preprocess {best[0] * 1e3:5.1f}, "
+    print(f"{'fp8mfma ' if FP8_MFMA else 'fp8 ' if FP8 else ''}batch {B:2d}: {B / tot:6.2f} items/s  ({tot * 1e3:7.1f} ms per batch: preprocess {best[0] * 1e3:5.1f}, "
           f"image->first-token {best[1] * 1e3:6.1f}, decode {best[2] * 1e3:7.1f} = {B * (N_NEW - 1) / best[2]:7.1f} tok/s)", flush=True)
 
 # ---- answers of different lengths (16..128 tokens, as eos would end them): static batches wait for their longest row,

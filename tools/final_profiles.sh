@@ -23,6 +23,7 @@ run() { echo "== $*" | tee -a $OUT/configs.txt; timeout -k 10 300 python -u "$@"
 run tools/bench_stage1.py
 run tools/bench_vcr.py
 run tools/bench_vcr.py fp8
+run tools/bench_vcr.py fp8mfma
 run tools/bench_batched.py
 run tools/bench_batched.py 32 fp8
 echo "all done"; cat $OUT/configs.txt | head -30

@@ -55,6 +55,7 @@ static LinearArgs mk_linear(const void* A, int lda, const void* W, int ldw, void
 
 // vz_tune_set(14, rows): from this many rows on a decode step's linears run on the 128^2 tile GEMM (65 = never)
 static int g_decode_tile_rows = 29;      // measured cross-over on the tiled weight copies (profiles/r02_rows.txt): MFMA weight stream 4.42 ms per step at 25 rows, 4.74 at 32; tile route 4.56 / 4.64
+static int g_fp8_prefill_min_rows = 768;   // vz_tune_set(22, rows): fewest prefill rows that take the fp8 MFMA path of a prefill_fp8 engine
 static int g_decode_sk_short = 8;      // vz_tune_set(15, v): split-K factor of the K = 4096 decode projections (QKV, O) on the tile-GEMM route
 static int vz_decode_splitk(int N, int K, int act) {
     // In situ (rocprofv3 of a 64-row step, profiles/r02_rows.txt) the 128^2 kernel is bound by the bytes its workgroups keep in flight
@@ -903,7 +904,8 @@ extern "C" int vz_llm_prefill_rows(vz_engine* e, int row0, const void* d_embeds,
     int rc = VZ_OK;
     // one Zephyr prefill linear: bf16 tile GEMM, or - weight_fp8 engine with vz_engine_prefill_fp8 on - the input rows quantised to e4m3
     // (one power-of-two scale per row) and the product on the fp8 MFMA against the e4m3 weight copy (gemm_fp8.hip)
-    const bool f8 = e->prefill_fp8 && tp_local(e) && vz_gemm_fp8_ok(rows, QKV, H, H, H) && vz_gemm_fp8_ok(rows, H, I, I, I) && vz_gemm_fp8_ok(rows, H, A, A, A);
+    // (below ~768 rows the quantiser launches and the shallow grids cost more than the fp8 MFMA saves: 330 rows 20.4 vs 18.6 ms, 1320 rows 37.5 vs 43.6)
+    const bool f8 = e->prefill_fp8 && rows >= g_fp8_prefill_min_rows && tp_local(e) && vz_gemm_fp8_ok(rows, QKV, H, H, H) && vz_gemm_fp8_ok(rows, H, I, I, I) && vz_gemm_fp8_ok(rows, H, A, A, A);
     // norm_w != null: Ain is the residual stream and the RMSNorm belongs to this linear (fp8: norm + quantiser in one launch)
     auto plin = [&](const bf16_t* Ain, const float* norm_w, const std::string& wname, int N, int K, void* Cout, int ldc, const bf16_t* res, int act) -> int {
         const bf16_t* W = WB(wname + ".w", (long)N * K);
@@ -1245,6 +1247,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 14) { g_decode_tile_rows = value; return VZ_OK; }
     if (knob == 19) { g_wide_mode = value; return VZ_OK; }
     if (knob == 21) { g_fp8_gemm_choice = value; return VZ_OK; }
+    if (knob == 22) { g_fp8_prefill_min_rows = value; return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }
     if (knob == 10) { if (value < 0 || value > 64) { vz_set_error("tune_set: decode attention splits must be 0..64"); return VZ_ERR_ARG; } g_attn_nsplit = value; return VZ_OK; }
