@@ -125,6 +125,18 @@ int vz_op_attention(const void* d_q, const void* d_k, const void* d_v, void* d_o
                     float scale, int causal, int q_pos0, int window, const int* d_kv_len,
                     vz_stream stream);
 
+/* The same operator given an fp32 workspace of `workspace_floats` elements: a launch with Sq <= 64 un-masked query rows,
+ * head_dim 512 and many keys (the Q-Former cross-attention of ref:vis_zephyr/model/multimodal_projector/builder.py:34-39,
+ * 32 queries x 576 visual tokens per tile) gives every 96 keys their own workgroup and merges the partial softmaxes in a second
+ * kernel (the split depends on Sk only: a row's result is independent of B).  Needs B*Hq*ceil(Sk/96)*Sq*516 floats; with less
+ * (or any other shape) it runs as vz_op_attention. */
+int vz_op_attention_split(const void* d_q, const void* d_k, const void* d_v, void* d_o,
+                          int B, int Sq, int Sk, int Hq, int Hkv, int head_dim,
+                          long q_bs, long q_ss, long q_hs, long k_bs, long k_ss, long k_hs,
+                          long v_bs, long v_ss, long v_hs, long o_bs, long o_ss, long o_hs,
+                          float scale, int causal, int q_pos0, int window, const int* d_kv_len,
+                          float* d_workspace, long workspace_floats, vz_stream stream);
+
 /* RoPE (rotate-half, hf:models/mistral/modeling_mistral.py:51-81) on the Q and K heads of a fused QKV row
  * [B*S, (Hq+2Hkv)*D] + append of K/V to the cache [B][Hkv][max_ctx][D].  d_pos / d_slot: int32 [B*S] position
  * id and cache slot of every token (slot < 0: token not cached).  d_q_out bf16 [B*S,Hq,D].  D = 128. */
@@ -288,6 +300,10 @@ int vz_engine_unset_weight(vz_engine* e, const char* name);
 int vz_llm_prefill_rows(vz_engine* e, int row0, const void* d_embeds, int B, int S, const int* h_seqlens, const int* d_pos,
                         float* d_logits_all, float* d_logits_last, vz_stream stream);
 int vz_llm_decode_set_row(vz_engine* e, int row, int token, int next_pos, int ctx_len, vz_stream stream);
+/* Batched admissions: prefill several requests together into spare cache rows (row0 >= the running batch), then move each one's
+ * first h_len[i] cache positions from row h_src[i] to the freed row h_dst[i] (every layer, K and V; stream-ordered).  Rows of
+ * one call must not overlap (no destination equal to another move's source or destination). */
+int vz_llm_kv_move_rows(vz_engine* e, int n, const int* h_src, const int* h_dst, const int* h_len, vz_stream stream);
 
 /* ---- anyres preprocessing on the device (ref:vis_zephyr/model/multi_scale_process.py:70-171) ----
  * vz_op_resample_u8: Pillow's 8-bit LANCZOS `Image.resize` (horizontal pass, 8-bit intermediate, vertical pass) of an

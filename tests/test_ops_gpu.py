@@ -245,6 +245,34 @@ def test_attention_softmax_spike(B):
     check_close("attention spike", out, _ref_attention(q, k, v, D ** -0.5, False, 0, 0, None), 8e-3, 4e-3)
 
 
+@pytest.mark.parametrize("T,Sq,Sk,split", [(5, 32, 576, 0), (5, 32, 576, 3), (1, 32, 576, 0), (2, 17, 100, 0), (3, 64, 1000, 7),
+                                           (24, 32, 576, 0)])
+def test_attention_key_split_q_former_cross(B, T, Sq, Sk, split):
+    """Q-Former cross-attention shape (32 queries x 576 visual tokens, 8 heads x 512) with the key tiles spread over
+    workgroups + combine kernel: against the fp32 reference and against the one-workgroup launch of the same inputs."""
+    H, D = 8, 512
+    q = _rand((T, Sq, H, D), 1.0, 60).bfloat16()
+    kv = _rand((T, Sk, 2 * H * D), 1.0, 61).bfloat16()          # K|V column slices of one projection, as the engine hands them
+    k, v = kv[:, :, :H * D].view(T, Sk, H, D), kv[:, :, H * D:].view(T, Sk, H, D)
+    k[0, Sk - 5] = (q[0, 3] * 3).bfloat16()                       # one dominating key inside the last split
+    nsplit = split if split >= 2 else ((Sk + 31) // 32 + 2) // 3
+    ws = torch.empty(T * H * nsplit * Sq * 516, dtype=torch.float32, device="cuda")
+    B.check(B.lib().vz_tune_set(23, split))
+    try:
+        out = B.attention(q, k, v, D ** -0.5, workspace=ws)
+    finally:
+        B.check(B.lib().vz_tune_set(23, 0))
+    one = B.attention(q, k, v, D ** -0.5)
+    ref = _ref_attention(q, k, v, D ** -0.5, False, 0, 0, None)
+    check_close(f"attention key-split T{T} {Sq}x{Sk}", out, ref, 8e-3, 4e-3)
+    check_close(f"attention key-split vs one workgroup T{T} {Sq}x{Sk}", out, one.float(), 8e-3, 4e-3)
+    # a workspace too small for any split falls back to the one-workgroup kernel: bit-identical
+    small = B.attention(q, k, v, D ** -0.5, workspace=ws[:1024])
+    assert torch.equal(small, one)
+    if split == 0 and T > 1:      # the split follows Sk only: a tile's rows do not change with the tiles beside it
+        assert torch.equal(B.attention(q[1:2], k[1:2], v[1:2], D ** -0.5, workspace=ws), out[1:2])
+
+
 def test_argmax_first_max(B):
     x = _rand((3, 32001), 1.0, 37)
     x[1, 777] = 50.0

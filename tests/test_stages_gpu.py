@@ -698,7 +698,7 @@ def test_continuous_batching_matches_static_batches(env):
     hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
     hf.mm_patch_merge_type = "flat"
     hf.mm_hidden_size = 5120
-    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=4, max_ctx=256, max_tiles=4, max_text=64)
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=6, max_ctx=256, max_tiles=4, max_text=64)
     lens = [9, 30, 17, 44, 12, 25, 38]
     budgets = [5, 21, 9, 33, 1, 18, 7]
     tiles = synth.synth_tiles(2, seed=3).to(model.device).bfloat16()
@@ -729,13 +729,21 @@ def test_continuous_batching_matches_static_batches(env):
         # an eos that request 1 emits at its 8th token (mid-chunk with sync_every = 4) and that hits nobody's first token
         eos = free_run[1][7]
         assume_ok = all(f[0] != eos for f in free_run.values())
-        got = dict(model.generate_stream(reqs, eos_token_id=[eos] if assume_ok else None, rows=3, sync_every=4))
-        assert sorted(got) == list(range(len(reqs)))
-        for i in range(len(reqs)):
-            want = free_run[i]
-            if assume_ok and eos in want:
-                want = want[: want.index(eos) + 1]
-            assert got[i].tolist() == want, f"request {i}: {got[i].tolist()} vs {want}"
+        # admit = 0: every request is prefilled alone, straight into its row; admit = None: the requests entering at one sync share
+        # one right-padded prefill in the 3 spare cache rows and their KV is moved to the freed rows (vz_llm_kv_move_rows);
+        # admit = 2: groups of two, so a sync with three free rows takes a batched and a single admission
+        for admit in (0, None, 2):
+            got = dict(model.generate_stream(reqs, eos_token_id=[eos] if assume_ok else None, rows=3, sync_every=4, admit=admit))
+            assert sorted(got) == list(range(len(reqs)))
+            for i in range(len(reqs)):
+                want = free_run[i]
+                if assume_ok and eos in want:
+                    want = want[: want.index(eos) + 1]
+                assert got[i].tolist() == want, f"admit={admit} request {i}: {got[i].tolist()} vs {want}"
+        with pytest.raises(ValueError):
+            next(model.generate_stream(reqs, rows=3, admit=4))            # only 3 spare rows
+        with pytest.raises(ValueError):
+            model.engine.kv_move_rows([4, 5], [0, 4], [8, 8])            # row 4 read by one move and written by the other
         # one row only degenerates to sequential generation and still agrees
         got1 = dict(model.generate_stream(reqs[:3], eos_token_id=None, rows=1, sync_every=16))
         for i in range(3):

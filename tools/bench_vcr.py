@@ -80,10 +80,13 @@ if "stream" in sys.argv[1:]:
         n_tok += sum(budgets[i0:i0 + ROWS])
     torch.cuda.synchronize()
     t_static = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    done = dict(model.generate_stream(reqs, eos_token_id=None, rows=ROWS, sync_every=16))
-    torch.cuda.synchronize()
-    t_stream = time.perf_counter() - t0
-    assert len(done) == n_items and all(len(done[i]) == budgets[i] for i in range(n_items))
+    res = {}
+    for admit in (0, None):                   # one prefill per admission / the admissions of one sync share a prefill in the spare cache rows
+        t0 = time.perf_counter()
+        done = dict(model.generate_stream(reqs, eos_token_id=None, rows=ROWS, sync_every=16, admit=admit))
+        torch.cuda.synchronize()
+        res[admit] = time.perf_counter() - t0
+        assert len(done) == n_items and all(len(done[i]) == budgets[i] for i in range(n_items))
     print(f"{'fp8 ' if FP8 else ''}{n_items} items, budgets 16..128 tokens ({n_tok} useful tokens), {ROWS} rows: static batches {n_items / t_static:6.2f} items/s, "
-          f"continuous batching {n_items / t_stream:6.2f} items/s ({t_static / t_stream:4.2f}x)", flush=True)
+          f"continuous batching {n_items / res[0]:6.2f} items/s ({t_static / res[0]:4.2f}x) with single admissions, "
+          f"{n_items / res[None]:6.2f} items/s ({t_static / res[None]:4.2f}x) with batched admissions", flush=True)

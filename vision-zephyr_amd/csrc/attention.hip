@@ -21,6 +21,8 @@
 // attn_decode_kernel + attn_decode_combine: one query token against the KV cache (HBM-bound,
 // split over the context so that B*Hq*nsplit workgroups stream the cache), lengths read from
 // device memory so that a captured hipGraph replays for every step.
+#include <algorithm>
+
 #include "vz_common.h"
 
 namespace {
@@ -34,9 +36,12 @@ struct FlashParams {
     int causal, q_pos0, window;
     const int* kv_len;
     long long* stamps;      // profiling only (vz_tune_set(16, 1)): stage cycle counts of wave 0 of the longest causal workgroup
+    float* part;            // SPLIT launches: [B][Hq][nsplit][Sq] x {o[HD], m, l}
 };
 
-template <int HD, int KT>
+// SPLIT (Sq <= 64, no mask): blockIdx.x cuts the key tiles instead of the query rows and the workgroup leaves its
+// un-normalised O, running maximum and normaliser in p.part for flash_split_combine.
+template <int HD, int KT, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void flash_attn_kernel(FlashParams p) {
     constexpr int KS_STRIDE = HD * 2 + 16;   // bytes per K row in LDS (+16: spreads the 16 rows of a fragment read)
     constexpr int VT_STRIDE = KT * 2 + 8;    // bytes per V^T row (d) in LDS
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(FlashParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = SPLIT ? 0 : blockIdx.x * 64;
     const int hk = h / (p.Hq / p.Hkv);
     const int kv_len = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
 
@@ -77,7 +82,12 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(FlashParams p) {
         k_end = min(k_end, last_q + 1);
         if (p.window > 0) k_begin = max(0, q0 + p.q_pos0 - p.window + 1);
     }
-    const int t_begin = k_begin / KT, t_end = (k_end + KT - 1) / KT;
+    int t_begin = k_begin / KT, t_end = (k_end + KT - 1) / KT;
+    if (SPLIT) {
+        const int per = (t_end - t_begin + (int)gridDim.x - 1) / (int)gridDim.x;
+        t_begin += (int)blockIdx.x * per;
+        t_end = min(t_end, t_begin + per);
+    }
 
     const bf16_t* kbase = p.k + (size_t)b * p.k_bs + (size_t)hk * p.k_hs;
     const bf16_t* vbase = p.v + (size_t)b * p.v_bs + (size_t)hk * p.v_hs;
@@ -174,6 +184,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(FlashParams p) {
     }
 
     // ---- epilogue: oacc[dt][r] = O[q = this lane's query][d = dt*16 + 4g + r] ----
+    if (SPLIT) {
+        if (q_valid) {
+            float* pp = p.part + ((((size_t)b * p.Hq + h) * gridDim.x + blockIdx.x) * p.Sq + qrow) * (HD + 4);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) *(f32x4*)(pp + dt * 16 + 4 * g) = oacc[dt];
+            if (g == 0) { pp[HD] = m_run; pp[HD + 1] = l_run; }
+        }
+        return;
+    }
     if (q_valid) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         bf16_t* op = p.o + (size_t)b * p.o_bs + (size_t)qrow * p.o_ss + (size_t)h * p.o_hs;
@@ -590,6 +609,30 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
     }
 }
 
+// grid (Sq, Hq, B), HD / 4 threads: merge the nsplit partial softmaxes of one query row (4 output columns per thread)
+template <int HD>
+__global__ __launch_bounds__(HD / 4) void flash_split_combine(FlashParams p, int nsplit) {
+    const int q = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x * 4;
+    const float* pp = p.part + ((((size_t)b * p.Hq + h) * nsplit) * p.Sq + q) * (HD + 4);
+    const size_t sstride = (size_t)p.Sq * (HD + 4);
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, pp[s * sstride + HD]);
+    float l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+        const float ms = pp[s * sstride + HD];
+        const float w = ms == -INFINITY ? 0.f : __expf(ms - m);
+        l += w * pp[s * sstride + HD + 1];
+        const f32x4 o = *(const f32x4*)(pp + s * sstride + d);
+        acc[0] += w * o[0]; acc[1] += w * o[1]; acc[2] += w * o[2]; acc[3] += w * o[3];
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    uint2 pk;
+    pk.x = pack_bf16x2(acc[0] * inv, acc[1] * inv);
+    pk.y = pack_bf16x2(acc[2] * inv, acc[3] * inv);
+    *(uint2*)(p.o + (size_t)b * p.o_bs + (size_t)q * p.o_ss + (size_t)h * p.o_hs + d) = pk;
+}
+
 static int g_attn_version = 3;     // 1 = v1 kernel for every head_dim (tests / A-B), 2 = v2 (head_dim 64 / 128) with the classic online-softmax step, 3 = v2 with the deferred-maximum step (production)
 template <int HD>
 int launch_flash2(const FlashParams& p, hipStream_t s) {
@@ -612,7 +655,22 @@ int launch_flash(const FlashParams& p, hipStream_t s) {
     constexpr int LDS = KT * (HD * 2 + 16) + HD * (KT * 2 + 8);
     { int r = vz_init_attention_kernels(); if (r) return r; }
     dim3 grid((p.Sq + 63) / 64, p.Hq, p.B);
-    hipLaunchKernelGGL((flash_attn_kernel<HD, KT>), grid, dim3(256), LDS, s, p);
+    hipLaunchKernelGGL((flash_attn_kernel<HD, KT, false>), grid, dim3(256), LDS, s, p);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
+int g_attn_split = 0;              // vz_tune_set(23, v): 0 = automatic key split of few-row head_dim-512 launches, 1 = never, n >= 2 = n splits
+
+// Few query rows against many keys (Q-Former cross-attention, 32 x 576 per tile and head): B * Hq workgroups alone leave most
+// of the chip idle and each one walks its 18 key tiles serially; with a workspace the key tiles are spread over ~one workgroup per CU.
+template <int HD, int KT>
+int launch_flash_split(const FlashParams& p, int nsplit, hipStream_t s) {
+    constexpr int LDS = KT * (HD * 2 + 16) + HD * (KT * 2 + 8);
+    { int r = vz_init_attention_kernels(); if (r) return r; }
+    hipLaunchKernelGGL((flash_attn_kernel<HD, KT, true>), dim3(nsplit, p.Hq, p.B), dim3(256), LDS, s, p);
+    VZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL((flash_split_combine<HD>), dim3(p.Sq, p.Hq, p.B), dim3(HD / 4), 0, s, p, nsplit);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
@@ -723,7 +781,8 @@ __global__ __launch_bounds__(128) void attn_decode_combine(const float* __restri
 template <int HD, int KT>
 static int set_flash_attr() {
     constexpr int LDS = KT * (HD * 2 + 16) + HD * (KT * 2 + 8);
-    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn_kernel<HD, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn_kernel<HD, KT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    if (HD == 512) VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn_kernel<HD, KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     return VZ_OK;
 }
 
@@ -736,6 +795,7 @@ int vz_attn_read_stamps(long long* host16) {          // 16 stage words + 2048 x
     return VZ_OK;
 }
 void vz_set_attn_version(int v) { g_attn_version = v; }
+void vz_set_attn_split(int v) { g_attn_split = v; }
 
 int vz_init_attention_kernels() {
     static bool done = false;
@@ -772,6 +832,17 @@ int vz_launch_attention(const AttnArgs& a, hipStream_t s) {
     p.v_bs = a.v_bs; p.v_ss = a.v_ss; p.v_hs = a.v_hs; p.o_bs = a.o_bs; p.o_ss = a.o_ss; p.o_hs = a.o_hs;
     p.scale = a.scale; p.causal = a.causal; p.q_pos0 = a.q_pos0; p.window = a.window; p.kv_len = a.kv_len;
     p.stamps = g_attn_stamp_on ? g_attn_stamps : nullptr;
+    p.part = nullptr;
+    if (a.head_dim == 512 && a.part && g_attn_split != 1 && a.Sq <= 64 && !a.causal && !a.kv_len) {
+        // the split is a function of Sk alone (three 32-key tiles per workgroup): a query row's result never depends on how many
+        // tiles or samples share the launch (tests/test_stages_gpu.py::test_continuous_batching_matches_static_batches)
+        const int ntiles = (a.Sk + 31) / 32;
+        const int nsplit = g_attn_split >= 2 ? std::min(g_attn_split, ntiles) : (ntiles >= 6 ? (ntiles + 2) / 3 : 1);
+        if (nsplit >= 2 && nsplit <= 1024 && (size_t)a.B * a.Hq * nsplit * a.Sq * (512 + 4) <= a.part_floats) {
+            p.part = a.part;
+            return launch_flash_split<512, 32>(p, nsplit, s);
+        }
+    }
     if (g_attn_version != 1) {
         if (a.head_dim == 64) return launch_flash2<64>(p, s);
         if (a.head_dim == 128) return launch_flash2<128>(p, s);

@@ -2,6 +2,8 @@
 // embedding gather / [vision;text] splice, CLIP patch im2col + token assembly, multi-layer
 // fusion, argmax.  All of them move 16 bytes per lane per access (8 bf16), one wave per row
 // where rows are 2-10 KiB, and do their arithmetic in fp32 with a single rounding to bf16.
+#include <algorithm>
+
 #include "vz_common.h"
 
 namespace {
@@ -155,6 +157,21 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict
     if (row >= rows) return;
     for (int k = lane * 8; k < cols; k += 512)
         *(uint4*)(dst + (size_t)row * dst_stride + k) = *(const uint4*)(src + (size_t)row * src_stride + k);
+}
+
+// The first len[z] tokens of KV-cache row src[z] -> row dst[z], every layer, K and V, every KV head in one launch
+// (cache: [layer][K|V][row][kv head][max_ctx][D]).  grid (4-KiB pieces of a head's len * D * 2 bytes, layers * 2 * Hkv, moves).
+__global__ __launch_bounds__(256) void kv_move_rows_kernel(bf16_t* __restrict__ kv, size_t layer_elems, int max_batch, int Hkv,
+                                                           int max_ctx, int D, KvMoves mv) {
+    const int z = blockIdx.z, y = blockIdx.y;
+    const int head = y % Hkv, half = (y / Hkv) & 1, layer = y / (2 * Hkv);
+    const size_t row_elems = (size_t)Hkv * max_ctx * D;
+    bf16_t* base = kv + (size_t)layer * layer_elems + (size_t)half * (layer_elems / 2) + (size_t)head * max_ctx * D;
+    const bf16_t* src = base + (size_t)mv.src[z] * row_elems;
+    bf16_t* dst = base + (size_t)mv.dst[z] * row_elems;
+    const long n = (long)mv.len[z] * D;
+    const long k = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (k < n) *(uint4*)(dst + k) = *(const uint4*)(src + k);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -341,6 +358,24 @@ int vz_launch_embed_tokens(const int* ids, int rows, int cols, const bf16_t* tab
 int vz_launch_copy_rows(const bf16_t* src, long src_stride, bf16_t* dst, long dst_stride, int rows, int cols, hipStream_t s) {
     VZ_CHECK_ARG(rows > 0 && cols % 8 == 0 && src_stride % 8 == 0 && dst_stride % 8 == 0, "copy_rows: bad shape");
     hipLaunchKernelGGL(copy_rows_kernel, dim3(rows_grid(rows)), dim3(256), 0, s, src, src_stride, dst, dst_stride, rows, cols);
+    VZ_LAUNCH_CHECK();
+    return VZ_OK;
+}
+
+int vz_launch_kv_move_rows(bf16_t* kv, size_t layer_elems, int n_layers, int max_batch, int Hkv, int max_ctx, int D, const KvMoves& mv,
+                           hipStream_t s) {
+    VZ_CHECK_ARG(kv && mv.n >= 1 && mv.n <= 16 && D % 8 == 0, "kv_move_rows: bad argument");
+    int longest = 0;
+    for (int i = 0; i < mv.n; ++i) {
+        VZ_CHECK_ARG(mv.src[i] >= 0 && mv.src[i] < max_batch && mv.dst[i] >= 0 && mv.dst[i] < max_batch && mv.src[i] != mv.dst[i] &&
+                         mv.len[i] >= 1 && mv.len[i] <= max_ctx, "kv_move_rows: move %d (%d -> %d, %d tokens) outside the cache", i, mv.src[i], mv.dst[i], mv.len[i]);
+        for (int j = 0; j < mv.n; ++j)       // a launch has no order between its moves: no row may be written twice or read after being written
+            VZ_CHECK_ARG(i == j || (mv.dst[i] != mv.dst[j] && mv.dst[i] != mv.src[j]), "kv_move_rows: moves %d and %d overlap", i, j);
+        longest = std::max(longest, mv.len[i]);
+    }
+    const long pieces = ((long)longest * D + 2047) / 2048;
+    hipLaunchKernelGGL(kv_move_rows_kernel, dim3((unsigned)pieces, (unsigned)(n_layers * 2 * Hkv), (unsigned)mv.n), dim3(256), 0, s, kv, layer_elems,
+                       max_batch, Hkv, max_ctx, D, mv);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }

@@ -38,7 +38,7 @@ void vz_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vz_last_error(void) { return g_err; }
-extern "C" int vz_abi_version(void) { return 7; }
+extern "C" int vz_abi_version(void) { return 9; }
 extern "C" const char* vz_target_arch(void) { return "gfx950"; }
 
 // ------------------------------------------------------------------------------------------------
@@ -149,6 +149,20 @@ extern "C" int vz_op_attention(const void* q, const void* k, const void* v, void
     a.q_bs = q_bs; a.q_ss = q_ss; a.q_hs = q_hs; a.k_bs = k_bs; a.k_ss = k_ss; a.k_hs = k_hs;
     a.v_bs = v_bs; a.v_ss = v_ss; a.v_hs = v_hs; a.o_bs = o_bs; a.o_ss = o_ss; a.o_hs = o_hs;
     a.scale = scale; a.causal = causal; a.q_pos0 = q_pos0; a.window = window; a.kv_len = kv_len;
+    return vz_launch_attention(a, (hipStream_t)s);
+}
+extern "C" int vz_op_attention_split(const void* q, const void* k, const void* v, void* o, int B, int Sq, int Sk, int Hq, int Hkv,
+                                     int head_dim, long q_bs, long q_ss, long q_hs, long k_bs, long k_ss, long k_hs, long v_bs,
+                                     long v_ss, long v_hs, long o_bs, long o_ss, long o_hs, float scale, int causal, int q_pos0,
+                                     int window, const int* kv_len, float* ws, long ws_floats, vz_stream s) {
+    VZ_CHECK_ARG(ws_floats >= 0 && (ws || ws_floats == 0) && ((uintptr_t)ws & 15) == 0, "attention_split: bad workspace");
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o;
+    a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = Hq; a.Hkv = Hkv; a.head_dim = head_dim;
+    a.q_bs = q_bs; a.q_ss = q_ss; a.q_hs = q_hs; a.k_bs = k_bs; a.k_ss = k_ss; a.k_hs = k_hs;
+    a.v_bs = v_bs; a.v_ss = v_ss; a.v_hs = v_hs; a.o_bs = o_bs; a.o_ss = o_ss; a.o_hs = o_hs;
+    a.scale = scale; a.causal = causal; a.q_pos0 = q_pos0; a.window = window; a.kv_len = kv_len;
+    a.part = ws; a.part_floats = (size_t)ws_floats;
     return vz_launch_attention(a, (hipStream_t)s);
 }
 extern "C" int vz_op_rope_kv(const void* qkv, int ld, void* q_out, void* kc, void* vc, const float* cosT, const float* sinT,
@@ -631,9 +645,10 @@ extern "C" int vz_clip_fused_features(vz_engine* e, const void* d_images, int T,
 // a11: Q-Former
 // ------------------------------------------------------------------------------------------------
 static int qf_attn(vz_engine* e, const bf16_t* q, long q_bs, long q_ss, const bf16_t* k, const bf16_t* v, long kv_bs, long kv_ss,
-                   bf16_t* o, int B, int Sq, int Sk, hipStream_t s) {
+                   bf16_t* o, int B, int Sq, int Sk, hipStream_t s, float* part = nullptr, size_t part_floats = 0) {
     ProfScope ps(e, K_ATTN, s);
     AttnArgs a;
+    a.part = part; a.part_floats = part_floats;
     a.q = q; a.k = k; a.v = v; a.o = o;
     a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = e->c.qf_heads; a.Hkv = e->c.qf_heads; a.head_dim = 512;
     a.q_bs = q_bs; a.q_ss = q_ss; a.q_hs = 512; a.k_bs = a.v_bs = kv_bs; a.k_ss = a.v_ss = kv_ss; a.k_hs = a.v_hs = 512;
@@ -663,6 +678,7 @@ extern "C" int vz_qformer(vz_engine* e, const void* d_feats, int T, const void* 
         m.take<bf16_t>((size_t)n_samples * N0 * H); m.take<bf16_t>((size_t)n_samples * N0 * H); m.take<bf16_t>((size_t)n_samples * N0 * 2 * H);
         m.take<bf16_t>((size_t)NQ * H); m.take<bf16_t>((size_t)n_samples * NQ * H); m.take<bf16_t>((size_t)n_samples * NQ * H);
         m.take<bf16_t>(R * H); m.take<bf16_t>(R * H); m.take<bf16_t>(R * 3 * H); m.take<bf16_t>(R * H); m.take<bf16_t>(R * FF);
+        m.take<float>((size_t)T * c.qf_heads * ((P + 95) / 96) * NQ * (512 + 4));
         need = m.off + 256;
     }
     RC(ensure_arena(e, need));
@@ -680,6 +696,8 @@ extern "C" int vz_qformer(vz_engine* e, const void* d_feats, int T, const void* 
     bf16_t* qkv = m.take<bf16_t>(R * 3 * H);
     bf16_t* att = m.take<bf16_t>(R * H);
     bf16_t* ff = m.take<bf16_t>(R * FF);
+    const size_t part_floats = (size_t)T * c.qf_heads * ((P + 95) / 96) * NQ * (512 + 4);   // key-split partials of the cross-attention (96 keys per workgroup)
+    float* part = m.take<float>(part_floats);
     int rc = VZ_OK;
     { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm((const bf16_t*)d_feats, KD, fn, KD, WF("qf.pre_norm.w", KD), WF("qf.pre_norm.b", KD), T * P, KD, c.qf_eps, s)); }
     const bf16_t* queries = WB("qf.queries", (long)NQ * H);
@@ -718,7 +736,7 @@ extern "C" int vz_qformer(vz_engine* e, const void* d_feats, int T, const void* 
         RC(linear(e, 0, fn, KD, WB(p + "ca_kv.w", 2L * H * KD), KD, ckv, 2 * H, T * P, 2 * H, KD, WF(p + "ca_kv.b", 2 * H), nullptr, 0, VZ_ACT_NONE, 0, s));
         { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(x, H, y, H, WF(p + "n2.w", H), WF(p + "n2.b", H), (int)R, H, c.qf_eps, s)); }
         RC(linear(e, 0, y, H, WB(p + "ca_q.w", (long)H * H), H, qkv, H, (int)R, H, H, WF(p + "ca_q.b", H), nullptr, 0, VZ_ACT_NONE, 0, s));
-        RC(qf_attn(e, qkv, (long)NQ * H, H, ckv, ckv + H, (long)P * 2 * H, 2 * H, att, T, NQ, P, s));
+        RC(qf_attn(e, qkv, (long)NQ * H, H, ckv, ckv + H, (long)P * 2 * H, 2 * H, att, T, NQ, P, s, part, part_floats));
         RC(linear(e, 0, att, H, WB(p + "ca_out.w", (long)H * H), H, x, H, (int)R, H, H, WF(p + "ca_out.b", H), x, H, VZ_ACT_NONE, 0, s));
         // FFN
         { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(x, H, y, H, WF(p + "n3.w", H), WF(p + "n3.b", H), (int)R, H, c.qf_eps, s)); }
@@ -1015,6 +1033,25 @@ extern "C" int vz_llm_decode_set_row(vz_engine* e, int row, int token, int next_
     return VZ_OK;
 }
 
+// Batched admissions: several requests are prefilled TOGETHER into spare cache rows (rows the running decode batch does not use,
+// vz_llm_prefill_rows with row0 >= the batch size) and then moved to whichever rows have come free - the first h_len[i] cache
+// positions of row h_src[i] to row h_dst[i], all layers, one launch per 16 moves, stream-ordered behind the prefill.
+extern "C" int vz_llm_kv_move_rows(vz_engine* e, int n, const int* h_src, const int* h_dst, const int* h_len, vz_stream stream) {
+    NEED_READY();
+    VZ_CHECK_ARG(n >= 1 && h_src && h_dst && h_len, "kv_move_rows: bad argument");
+    const vz_config& c = e->c;
+    for (int i = 0; i < n; ++i)
+        VZ_CHECK_ARG(e->dec_B == 0 || h_src[i] >= e->dec_B || e->h_parked[h_src[i]], "kv_move_rows: source row %d belongs to the running decode batch", h_src[i]);
+    for (int i0 = 0; i0 < n; i0 += 16) {
+        KvMoves mv;
+        mv.n = std::min(16, n - i0);
+        for (int i = 0; i < mv.n; ++i) { mv.src[i] = h_src[i0 + i]; mv.dst[i] = h_dst[i0 + i]; mv.len[i] = h_len[i0 + i]; }
+        int r = vz_launch_kv_move_rows(e->kv, e->kv_layer_elems, c.n_layers, c.max_batch, e->Hkv_l, c.max_ctx, c.head_dim, mv, (hipStream_t)stream);
+        if (r) return r;
+    }
+    return VZ_OK;
+}
+
 // one decode step, all launches on `s`; every quantity that changes between steps lives in device memory
 static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, float* d_logits_dbg, hipStream_t s) {
     const vz_config& c = e->c;
@@ -1248,6 +1285,8 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 19) { g_wide_mode = value; return VZ_OK; }
     if (knob == 21) { g_fp8_gemm_choice = value; return VZ_OK; }
     if (knob == 22) { g_fp8_prefill_min_rows = value; return VZ_OK; }
+    if (knob == 23) { vz_set_attn_split(value); return VZ_OK; }
+    if (knob == 24) { vz_set_splitk_cap(value); return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }
     if (knob == 10) { if (value < 0 || value > 64) { vz_set_error("tune_set: decode attention splits must be 0..64"); return VZ_ERR_ARG; } g_attn_nsplit = value; return VZ_OK; }

@@ -370,6 +370,8 @@ static int g_gemm_choice = 0;
 void vz_set_gemm_choice(int v) { g_gemm_choice = v; }
 static int g_splitk_mode = 0;          // 0 auto, 1 never (A/B knob 3)
 void vz_set_splitk_mode(int v) { g_splitk_mode = v; }
+static int g_splitk_cap = 8;           // most K slices of a weight-streaming (M <= 512) product (A/B knob 24; 4 -> 8: Q-Former 3.87 -> 3.80 ms)
+void vz_set_splitk_cap(int v) { g_splitk_cap = v < 1 ? 1 : (v > 16 ? 16 : v); }
 // g_slab / g_slab_bytes (declared above): process-wide split-K workspace, 96 MiB up front, grown on demand outside captures
 
 // Tile choice: the 256x256 8-phase kernel runs one workgroup per CU, so it needs enough 256^2 tiles to fill the
@@ -406,7 +408,7 @@ int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
     (void)tiles;
     if (g_splitk_mode != 1 && a.M <= 512 && p.tiles_n < 128 && a.act != VZ_ACT_SWIGLU && (a.N & 3) == 0) {
         splitk = (256 + p.tiles_n - 1) / p.tiles_n;
-        if (splitk > 4) splitk = 4;
+        if (splitk > g_splitk_cap) splitk = g_splitk_cap;
         while (splitk > 1 && nk / splitk < 8) --splitk;
     }
     if (a.splitk_hint > 0 && (a.N & 7) == 0) {       // decode batches (see LinearArgs.splitk_hint); SwiGLU pairs are formed in the finalize kernel

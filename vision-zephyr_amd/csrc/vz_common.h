@@ -191,7 +191,8 @@ int vz_init_gemm256_kernel();
 int vz_gemm256_async_error(hipStream_t s, int* err, bool reset_only);
 int vz_gemm256_corrupt_tickets(hipStream_t s, int tr, int arrive, int ready);
 void vz_set_gemm_choice(int v);
-void vz_set_splitk_mode(int v);   // 0 auto, 1 force 128x128, 2 force 256x256
+void vz_set_splitk_mode(int v);
+void vz_set_splitk_cap(int v);   // 0 auto, 1 force 128x128, 2 force 256x256
 int vz_launch_linear(const LinearArgs& a, hipStream_t s);  // picks by M
 
 int vz_launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const float* w, const float* b, int rows,
@@ -207,9 +208,14 @@ struct AttnArgs {
     float scale;
     int causal, q_pos0, window;
     const int* kv_len;
+    // optional fp32 workspace: lets a launch with few query rows and a long key range (Q-Former cross-attention: 32 x 576,
+    // head_dim 512) split the keys over several workgroups and merge the partial softmaxes in a second kernel
+    float* part = nullptr;
+    size_t part_floats = 0;
 };
 int vz_launch_attention(const AttnArgs& a, hipStream_t s);
 void vz_set_attn_version(int v);
+void vz_set_attn_split(int v);
 
 // decode attention: one query token per slot against the KV cache; lengths live on the device
 struct AttnDecodeArgs {
@@ -259,6 +265,10 @@ int vz_init_gemm_kernels();
 int vz_init_attention_kernels();
 int vz_launch_copy_rows(const bf16_t* src, long src_stride, bf16_t* dst, long dst_stride, int rows, int cols,
                         hipStream_t s);
+// KV-cache row moves (batched admissions of the continuous-batching loop): up to 16 (src row, dst row, tokens) triples per launch
+struct KvMoves { int n; int src[16], dst[16], len[16]; };
+int vz_launch_kv_move_rows(bf16_t* kv, size_t layer_elems, int n_layers, int max_batch, int Hkv, int max_ctx, int D, const KvMoves& mv,
+                           hipStream_t s);
 int vz_launch_step_advance(int* step, hipStream_t s);
 int vz_launch_repack_logits(const float* gathered, float* out, int rows, int Vp, int V, int tp, hipStream_t s);
 

@@ -418,12 +418,18 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
 
     # ---- continuous batching: the 23 K-item eval loop without waiting for a batch's longest answer ----
     @torch.no_grad()
-    def generate_stream(self, requests, max_new_tokens: int = 128, eos_token_id=None, rows: Optional[int] = None, sync_every: int = 16):
+    def generate_stream(self, requests, max_new_tokens: int = 128, eos_token_id=None, rows: Optional[int] = None, sync_every: int = 16,
+                        admit: Optional[int] = None):
         """Greedy generation over an iterable of requests - dicts with `input_ids` [1, L] (IMAGE_TOKEN_INDEX sentinels allowed),
         optional `images` ([N,3,336,336]) / `images_size`, optional `max_new_tokens` - with CONTINUOUS batching: up to `rows`
         KV-cache rows decode together; a row whose sequence ends (eos or its token budget) is re-armed with the next request at
         the next host sync (every `sync_every` steps), the other rows keep decoding.  Yields `(index, LongTensor[n_new])` in
-        completion order; every sequence gets exactly the tokens `generate` gives it alone (rows are independent)."""
+        completion order; every sequence gets the tokens `generate` gives it alone (rows are independent).
+
+        Admissions are BATCHED when the engine has cache rows to spare (`max_batch > rows`): all requests entering at one sync
+        share one Zephyr prefill (right-padded, up to `admit` = min(max_batch - rows, 16) sequences) into the spare rows, one
+        argmax readback, and their KV is then moved to the freed rows (`vz_llm_kv_move_rows`).  The vision stage stays per request:
+        the Q-Former's text conditioning makes a request's visual tokens depend on the padded length of its batch."""
         from vz_hip import binding as B
         self._kv_epoch += 1
         self._ensure_ready()
@@ -434,37 +440,71 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         n_rows = min(eng.max_batch, 64) if rows is None else int(rows)
         if not 1 <= n_rows <= min(eng.max_batch, 64):
             raise ValueError(f"rows must be in [1, {min(eng.max_batch, 64)}]")
+        spare = eng.max_batch - n_rows
+        width = min(spare, 16) if admit is None else int(admit)
+        if not 0 <= width <= min(spare, 16):
+            raise ValueError(f"admit must be in [0, {min(spare, 16)}] (max_batch {eng.max_batch} - rows {n_rows} spare cache rows)")
         it = iter(enumerate(requests))
         slots = [None] * n_rows                 # per row: [request index, tokens so far, budget]
         eng.decode_begin(torch.zeros(n_rows, dtype=torch.int32), [0] * n_rows, [0] * n_rows)       # every row parked
         exhausted = False
+
+        def embed(idx, req):
+            ids = req["input_ids"]
+            ids = ids if ids.dim() == 2 else ids.unsqueeze(0)
+            images = req.get("images")
+            budget = int(req.get("max_new_tokens", max_new_tokens))
+            if images is not None:
+                images = images if isinstance(images, (list, tuple)) else [images]
+                emb = self.prepare_inputs_labels_for_multimodal(ids.to(self.device), None, None, None, None, images,
+                                                                req.get("images_size"))[4]
+            else:
+                emb = eng.embed_tokens(ids.to(self.device))
+            S = emb.shape[1]
+            if S + budget > eng.max_ctx:
+                raise ValueError(f"request {idx}: prompt ({S}) + max_new_tokens ({budget}) exceeds the engine's max_ctx ({eng.max_ctx})")
+            return emb, S, budget
+
         while True:
-            for r in range(n_rows):             # admit requests into free rows
-                while slots[r] is None and not exhausted:
+            while not exhausted:                # admit requests into free rows
+                free = [r for r in range(n_rows) if slots[r] is None]
+                if not free:
+                    break
+                group = []
+                while len(group) < (min(len(free), width) if width >= 2 else 1):
                     try:
                         idx, req = next(it)
                     except StopIteration:
                         exhausted = True
                         break
-                    ids = req["input_ids"]
-                    ids = ids if ids.dim() == 2 else ids.unsqueeze(0)
-                    images = req.get("images")
-                    budget = int(req.get("max_new_tokens", max_new_tokens))
-                    if images is not None:
-                        images = images if isinstance(images, (list, tuple)) else [images]
-                        emb = self.prepare_inputs_labels_for_multimodal(ids.to(self.device), None, None, None, None, images,
-                                                                        req.get("images_size"))[4]
-                    else:
-                        emb = eng.embed_tokens(ids.to(self.device))
-                    S = emb.shape[1]
-                    if S + budget > eng.max_ctx:
-                        raise ValueError(f"request {idx}: prompt ({S}) + max_new_tokens ({budget}) exceeds the engine's max_ctx ({eng.max_ctx})")
-                    first = int(B.argmax(eng.prefill_rows(r, emb, [S]))[0])
+                    group.append((idx,) + embed(idx, req))
+                if not group:
+                    break
+                if len(group) == 1:             # straight into the free row
+                    idx, emb, S, budget = group[0]
+                    firsts = [int(B.argmax(eng.prefill_rows(free[0], emb, [S]))[0])]
+                else:                           # one prefill for the group in the spare rows, one readback
+                    Smax = max(g[2] for g in group)
+                    pad = torch.zeros(len(group), Smax, group[0][1].shape[-1], dtype=torch.bfloat16, device=self.device)
+                    for j, g in enumerate(group):
+                        pad[j, :g[2]] = g[1][0]
+                    firsts = B.argmax(eng.prefill_rows(n_rows, pad, [g[2] for g in group])).tolist()
+                moves = []
+                for j, (idx, emb, S, budget) in enumerate(group):
+                    first = int(firsts[j])
                     if first in eos or budget <= 1:
                         yield idx, torch.tensor([first], dtype=torch.long)
                         continue
-                    eng.decode_set_row(r, first, S, S)
+                    r = free.pop(0)
+                    if len(group) > 1:
+                        moves.append((n_rows + j, r, S))
                     slots[r] = [idx, [first], budget]
+                    group[j] = (idx, None, S, budget, r, first)
+                if moves:
+                    eng.kv_move_rows([m[0] for m in moves], [m[1] for m in moves], [m[2] for m in moves])
+                for g in group:
+                    if len(g) == 6:
+                        eng.decode_set_row(g[4], g[5], g[2], g[2])
             if all(s is None for s in slots):
                 return
             n = min([sync_every] + [s[2] - len(s[1]) for s in slots if s is not None])

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libviszephyr_hip.so")
 
 VZ_OK, VZ_ERR_ARG, VZ_ERR_HIP, VZ_ERR_STATE, VZ_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 VZ_ASYNC_STREAMK = 2
-ABI_VERSION = 7
+ABI_VERSION = 9
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
 K_GEMM, K_GEMV, K_ATTN, K_ATTN_DEC, K_NORM, K_OTHER, K_FUSED, K_COMM = range(8)
 
@@ -55,6 +55,7 @@ SYMBOLS = {
     "vz_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _P]),
     "vz_op_rmsnorm": (_I, [_P, _I, _P, _I, _P, _I, _I, _F, _P]),
     "vz_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I] + [_L] * 12 + [_F, _I, _I, _I, _P, _P]),
+    "vz_op_attention_split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I] + [_L] * 12 + [_F, _I, _I, _I, _P, _P, _L, _P]),
     "vz_op_argmax": (_I, [_P, _I, _I, _P, _P]),
     "vz_op_rope_kv": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vz_op_attention_decode": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
@@ -72,6 +73,7 @@ SYMBOLS = {
     "vz_llm_prefill": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int), _P, _P, _P, _P]),
     "vz_llm_prefill_rows": (_I, [_P, _I, _P, _I, _I, C.POINTER(C.c_int), _P, _P, _P, _P]),
     "vz_llm_decode_set_row": (_I, [_P, _I, _I, _I, _I, _P]),
+    "vz_llm_kv_move_rows": (_I, [_P, _I, _P, _P, _P, _P]),
     "vz_llm_decode_begin": (_I, [_P, _I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
     "vz_llm_decode_mode": (_I, [_P, _P, _P]),
@@ -311,8 +313,9 @@ def rmsnorm(x, w, eps):
     return y
 
 
-def attention(q, k, v, scale, causal=False, q_pos0=0, window=0, kv_len=None):
-    """q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (any strides with unit stride on D) -> [B,Sq,Hq,D]."""
+def attention(q, k, v, scale, causal=False, q_pos0=0, window=0, kv_len=None, workspace=None):
+    """q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (any strides with unit stride on D) -> [B,Sq,Hq,D].
+    workspace: fp32 tensor; lets a few-row head_dim-512 launch split its keys over workgroups (vz_op_attention_split)."""
     _need_cuda(q, k, v, kv_len)
     B, Sq, Hq, D = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
@@ -321,6 +324,15 @@ def attention(q, k, v, scale, causal=False, q_pos0=0, window=0, kv_len=None):
     o = torch.empty(B, Sq, Hq, D, dtype=torch.bfloat16, device=q.device)
     if kv_len is not None:
         assert kv_len.dtype == torch.int32
+    if workspace is not None:
+        _need_cuda(workspace)
+        assert workspace.dtype == torch.float32 and workspace.is_contiguous()
+        check(lib().vz_op_attention_split(ptr(q), ptr(k), ptr(v), ptr(o), B, Sq, Sk, Hq, Hkv, D,
+                                          q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                                          v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2),
+                                          float(scale), int(causal), q_pos0, window, ptr(kv_len), ptr(workspace),
+                                          workspace.numel(), stream_ptr(q.device)))
+        return o
     check(lib().vz_op_attention(ptr(q), ptr(k), ptr(v), ptr(o), B, Sq, Sk, Hq, Hkv, D,
                                 q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                                 v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2),

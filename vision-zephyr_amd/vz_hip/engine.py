@@ -462,6 +462,13 @@ class Engine:
         B.check(self.lib.vz_llm_prefill_rows(self.h, int(row0), B.ptr(x), Bn, S, sl, B.ptr(pos), None, B.ptr(ll), self._s()))
         return ll
 
+    def kv_move_rows(self, src: Sequence[int], dst: Sequence[int], lens: Sequence[int]):
+        """first lens[i] cache positions of row src[i] -> row dst[i] (all layers), stream-ordered behind the prefill that wrote them."""
+        n = len(src)
+        assert n == len(dst) == len(lens) and n >= 1
+        arr = lambda v: (C.c_int * n)(*[int(x) for x in v])    # noqa: E731
+        B.check(self.lib.vz_llm_kv_move_rows(self.h, n, arr(src), arr(dst), arr(lens), self._s()))
+
     def decode_set_row(self, row: int, token: int, next_pos: int, ctx_len: int):
         """(re)arm one row of the running decode batch; ctx_len 0 parks it."""
         B.check(self.lib.vz_llm_decode_set_row(self.h, int(row), int(token), int(next_pos), int(ctx_len), self._s()))
