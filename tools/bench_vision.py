@@ -46,7 +46,7 @@ def main():
             for k, v in knobs:
                 B.check(B.lib().vz_tune_set(k, v))
             row.append(f"{name} {timed(lambda: eng.qformer(feats, None, ts)):6.3f} ms")
-        B.check(B.lib().vz_tune_set(23, 0)); B.check(B.lib().vz_tune_set(24, 4))
+        B.check(B.lib().vz_tune_set(23, 0)); B.check(B.lib().vz_tune_set(24, 8))
         print("   ".join(row), flush=True)
 
 
