@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """CLIP tower + Q-Former of the 5-tile bench workload, timed per stage with HIP events (one process, interleaved A/B of the
-knobs that only touch these stages: 23 = key split of the Q-Former cross-attention, 24 = split-K cap of its 160-row linears).
+knobs that only touch these stages: 23 = key split of the Q-Former cross-attention, 24 = split-K cap of its 160-row linears,
+25 = cross-attention K|V projections of all blocks as one GEMM).
 
     python tools/bench_vision.py [tiles]"""
 import os
@@ -41,12 +42,12 @@ def main():
     for rnd in range(3):
         clip = timed(lambda: eng.clip_fused_features(tiles))
         row = [f"clip {clip:6.3f} ms"]
-        for name, knobs in (("qformer base (no key split, 4 slices)", ((23, 1), (24, 4))), ("key split", ((23, 0), (24, 4))),
-                            ("key split + 8 slices", ((23, 0), (24, 8))), ("key split + 6 slices", ((23, 0), (24, 6)))):
+        for name, knobs in (("qformer base (no key split, 4 slices, K|V per block)", ((23, 1), (24, 4), (25, 0))), ("key split", ((23, 0), (24, 4), (25, 0))),
+                            ("+ 8 slices", ((23, 0), (24, 8), (25, 0))), ("+ K|V of all blocks in one GEMM", ((23, 0), (24, 8), (25, 1)))):
             for k, v in knobs:
                 B.check(B.lib().vz_tune_set(k, v))
             row.append(f"{name} {timed(lambda: eng.qformer(feats, None, ts)):6.3f} ms")
-        B.check(B.lib().vz_tune_set(23, 0)); B.check(B.lib().vz_tune_set(24, 8))
+        B.check(B.lib().vz_tune_set(23, 0)); B.check(B.lib().vz_tune_set(24, 8)); B.check(B.lib().vz_tune_set(25, 1))
         print("   ".join(row), flush=True)
 
 

@@ -644,6 +644,7 @@ extern "C" int vz_clip_fused_features(vz_engine* e, const void* d_images, int T,
 // ------------------------------------------------------------------------------------------------
 // a11: Q-Former
 // ------------------------------------------------------------------------------------------------
+static int g_qf_kv_all = 1;     // vz_tune_set(25, 0): the Q-Former's cross-attention K|V projections one block at a time (A/B)
 static int qf_attn(vz_engine* e, const bf16_t* q, long q_bs, long q_ss, const bf16_t* k, const bf16_t* v, long kv_bs, long kv_ss,
                    bf16_t* o, int B, int Sq, int Sk, hipStream_t s, float* part = nullptr, size_t part_floats = 0) {
     ProfScope ps(e, K_ATTN, s);
@@ -671,20 +672,35 @@ extern "C" int vz_qformer(vz_engine* e, const void* d_feats, int T, const void* 
     const int P = (c.clip_image / c.clip_patch) * (c.clip_image / c.clip_patch) + (c.clip_keep_cls ? 1 : 0);   // visual tokens per tile
     const int N0 = NQ + Lmax, FF = 2 * H;
     const size_t R = (size_t)T * NQ;  // query rows in flight after block 0's self-attention
+    int rc = VZ_OK;
+    // The cross-attention K|V projections of all blocks read the same pre-normed features.  When their weights (and biases) lie back
+    // to back in memory (vz_hip/engine.py allocates them so; a C-ABI caller may too) they run as ONE product over N = blocks * 2H:
+    // 256 column tiles per row tile = whole residency rounds of the 256^2 kernel, no stream-K tail (8 x 217 us -> one launch).  The
+    // [T * P, blocks * 2H] result is capped at 2 GiB; larger tile batches fill the chip per block anyway.
+    const int nb = c.qf_blocks;
+    const bf16_t* kvw0 = WB("qf.0.ca_kv.w", 2L * H * KD);
+    const float* kvb0 = WF("qf.0.ca_kv.b", 2 * H);
+    bool kv_all = nb > 1 && (size_t)T * P * nb * 2 * H * sizeof(bf16_t) <= ((size_t)2 << 30) && g_qf_kv_all;
+    for (int i = 1; i < nb && kv_all && !rc; ++i) {
+        const std::string p = "qf." + std::to_string(i) + ".";
+        kv_all = WB(p + "ca_kv.w", 2L * H * KD) == kvw0 + (size_t)i * 2 * H * KD && WF(p + "ca_kv.b", 2 * H) == kvb0 + (size_t)i * 2 * H;
+    }
+    if (rc) return rc;
+    const int kv_ld = kv_all ? nb * 2 * H : 2 * H;
     size_t need;
     {
         Carver m(nullptr, ~(size_t)0);
-        m.take<bf16_t>((size_t)T * P * KD); m.take<bf16_t>((size_t)T * P * 2 * H);
+        m.take<bf16_t>((size_t)T * P * KD); m.take<bf16_t>((size_t)T * P * kv_ld);
         m.take<bf16_t>((size_t)n_samples * N0 * H); m.take<bf16_t>((size_t)n_samples * N0 * H); m.take<bf16_t>((size_t)n_samples * N0 * 2 * H);
         m.take<bf16_t>((size_t)NQ * H); m.take<bf16_t>((size_t)n_samples * NQ * H); m.take<bf16_t>((size_t)n_samples * NQ * H);
         m.take<bf16_t>(R * H); m.take<bf16_t>(R * H); m.take<bf16_t>(R * 3 * H); m.take<bf16_t>(R * H); m.take<bf16_t>(R * FF);
-        m.take<float>((size_t)T * c.qf_heads * ((P + 95) / 96) * NQ * (512 + 4));
+        m.take<float>(std::max((size_t)T * ((P + 95) / 96), (size_t)n_samples * ((N0 + 95) / 96)) * c.qf_heads * NQ * (512 + 4));
         need = m.off + 256;
     }
     RC(ensure_arena(e, need));
     Carver m(e->arena, e->arena_bytes);
     bf16_t* fn = m.take<bf16_t>((size_t)T * P * KD);            // pre_norm(features)
-    bf16_t* ckv = m.take<bf16_t>((size_t)T * P * 2 * H);        // cross-attention K|V of the current block
+    bf16_t* ckv = m.take<bf16_t>((size_t)T * P * kv_ld);        // cross-attention K|V of the current block (kv_all: of every block)
     bf16_t* x0 = m.take<bf16_t>((size_t)n_samples * N0 * H);    // [queries ; text] per sample
     bf16_t* y0 = m.take<bf16_t>((size_t)n_samples * N0 * H);
     bf16_t* kv0 = m.take<bf16_t>((size_t)n_samples * N0 * 2 * H);
@@ -696,9 +712,9 @@ extern "C" int vz_qformer(vz_engine* e, const void* d_feats, int T, const void* 
     bf16_t* qkv = m.take<bf16_t>(R * 3 * H);
     bf16_t* att = m.take<bf16_t>(R * H);
     bf16_t* ff = m.take<bf16_t>(R * FF);
-    const size_t part_floats = (size_t)T * c.qf_heads * ((P + 95) / 96) * NQ * (512 + 4);   // key-split partials of the cross-attention (96 keys per workgroup)
+    // key-split partials (96 keys per workgroup) of the cross-attention and of block 0's self-attention over [queries ; text]
+    const size_t part_floats = std::max((size_t)T * ((P + 95) / 96), (size_t)n_samples * ((N0 + 95) / 96)) * c.qf_heads * NQ * (512 + 4);
     float* part = m.take<float>(part_floats);
-    int rc = VZ_OK;
     { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm((const bf16_t*)d_feats, KD, fn, KD, WF("qf.pre_norm.w", KD), WF("qf.pre_norm.b", KD), T * P, KD, c.qf_eps, s)); }
     const bf16_t* queries = WB("qf.queries", (long)NQ * H);
     if (rc) return rc;
@@ -719,7 +735,7 @@ extern "C" int vz_qformer(vz_engine* e, const void* d_feats, int T, const void* 
         { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(x0, H, y0, H, WF(p + "n1.w", H), WF(p + "n1.b", H), n_samples * N0, H, c.qf_eps, s)); }
         RC(linear(e, 0, y0, H, w_in + (size_t)H * H, H, kv0, 2 * H, n_samples * N0, 2 * H, H, b_in + H, nullptr, 0, VZ_ACT_NONE, 0, s));
         RC(linear(e, 0, y0, H, w_in, H, q0, H, NQ, H, H, b_in, nullptr, 0, VZ_ACT_NONE, 0, s));  // rows 0..31 of sample 0 = LN1(queries)
-        RC(qf_attn(e, q0, 0, H, kv0, kv0 + H, (long)N0 * 2 * H, 2 * H, a0, n_samples, NQ, N0, s));
+        RC(qf_attn(e, q0, 0, H, kv0, kv0 + H, (long)N0 * 2 * H, 2 * H, a0, n_samples, NQ, N0, s, part, part_floats));
         RC(linear(e, 0, a0, H, WB(p + "sa_out.w", (long)H * H), H, xs, H, n_samples * NQ, H, H, WF(p + "sa_out.b", H), xs, H, VZ_ACT_NONE, 0, s));
         ProfScope ps(e, K_OTHER, s);
         for (int t = 0; t < T; ++t) RC(vz_launch_copy_rows(xs + (size_t)h_tile_sample[t] * NQ * H, H, x + (size_t)t * NQ * H, H, NQ, H, s));
@@ -733,10 +749,12 @@ extern "C" int vz_qformer(vz_engine* e, const void* d_feats, int T, const void* 
             RC(linear(e, 0, att, H, WB(p + "sa_out.w", (long)H * H), H, x, H, (int)R, H, H, WF(p + "sa_out.b", H), x, H, VZ_ACT_NONE, 0, s));
         }
         // cross-attention against the tile's 576 fused visual tokens
-        RC(linear(e, 0, fn, KD, WB(p + "ca_kv.w", 2L * H * KD), KD, ckv, 2 * H, T * P, 2 * H, KD, WF(p + "ca_kv.b", 2 * H), nullptr, 0, VZ_ACT_NONE, 0, s));
+        if (!kv_all) RC(linear(e, 0, fn, KD, WB(p + "ca_kv.w", 2L * H * KD), KD, ckv, 2 * H, T * P, 2 * H, KD, WF(p + "ca_kv.b", 2 * H), nullptr, 0, VZ_ACT_NONE, 0, s));
+        else if (i == 0) RC(linear(e, 0, fn, KD, kvw0, KD, ckv, kv_ld, T * P, kv_ld, KD, kvb0, nullptr, 0, VZ_ACT_NONE, 0, s));
+        const bf16_t* ck = kv_all ? ckv + (size_t)i * 2 * H : ckv;
         { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(x, H, y, H, WF(p + "n2.w", H), WF(p + "n2.b", H), (int)R, H, c.qf_eps, s)); }
         RC(linear(e, 0, y, H, WB(p + "ca_q.w", (long)H * H), H, qkv, H, (int)R, H, H, WF(p + "ca_q.b", H), nullptr, 0, VZ_ACT_NONE, 0, s));
-        RC(qf_attn(e, qkv, (long)NQ * H, H, ckv, ckv + H, (long)P * 2 * H, 2 * H, att, T, NQ, P, s, part, part_floats));
+        RC(qf_attn(e, qkv, (long)NQ * H, H, ck, ck + H, (long)P * kv_ld, kv_ld, att, T, NQ, P, s, part, part_floats));
         RC(linear(e, 0, att, H, WB(p + "ca_out.w", (long)H * H), H, x, H, (int)R, H, H, WF(p + "ca_out.b", H), x, H, VZ_ACT_NONE, 0, s));
         // FFN
         { ProfScope ps(e, K_NORM, s); RC(vz_launch_layernorm(x, H, y, H, WF(p + "n3.w", H), WF(p + "n3.b", H), (int)R, H, c.qf_eps, s)); }
@@ -1287,6 +1305,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 22) { g_fp8_prefill_min_rows = value; return VZ_OK; }
     if (knob == 23) { vz_set_attn_split(value); return VZ_OK; }
     if (knob == 24) { vz_set_splitk_cap(value); return VZ_OK; }
+    if (knob == 25) { g_qf_kv_all = value; return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }
     if (knob == 10) { if (value < 0 || value > 64) { vz_set_error("tune_set: decode attention splits must be 0..64"); return VZ_ERR_ARG; } g_attn_nsplit = value; return VZ_OK; }

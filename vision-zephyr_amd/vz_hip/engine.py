@@ -41,6 +41,7 @@ class Engine:
     def __init__(self, cfg: ArchConfig, device="cuda:0", max_batch: int = 1, max_ctx: int = 4096,
                  max_tiles: int = 8, max_text: int = 2048, tp_size: int = 1, tp_rank: int = 0, weight_fp8: bool = False):
         self.lib = B.load_library()            # raises when the HIP library is absent: no fallback
+        self._qf_kv_pool = {}
         if not torch.cuda.is_available():
             raise RuntimeError("vz_hip.Engine needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.cfg = cfg
@@ -113,11 +114,23 @@ class Engine:
                 self._registered.discard(n)
                 B.check(self.lib.vz_engine_unset_weight(self.h, n.encode()))
 
+    _QF_KV = re.compile(r"qf\.(\d+)\.ca_kv\.(w|b)$")
+
     def _dest(self, name: str, shape, dtype) -> torch.Tensor:
         self._drop_fp8_copy(name)
         t = self.w.get(name)
         if t is None:
-            t = torch.zeros(*shape, dtype=dtype, device=self.device)
+            m = self._QF_KV.match(name)
+            if m:
+                # the cross-attention K|V projections of all Q-Former blocks read the same pre-normed visual features: laid out back
+                # to back (block-major), vz_qformer runs them as ONE GEMM over N = blocks * 2H (whole 256^2 tiles, no stream-K tail)
+                pool = self._qf_kv_pool.get(m.group(2))
+                if pool is None:
+                    pool = torch.zeros(self.cfg.qf_blocks, *shape, dtype=dtype, device=self.device)
+                    self._qf_kv_pool[m.group(2)] = pool
+                t = pool[int(m.group(1))]
+            else:
+                t = torch.zeros(*shape, dtype=dtype, device=self.device)
             self.w[name] = t
         return t
 
