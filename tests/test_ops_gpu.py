@@ -273,6 +273,24 @@ def test_attention_key_split_q_former_cross(B, T, Sq, Sk, split):
         assert torch.equal(B.attention(q[1:2], k[1:2], v[1:2], D ** -0.5, workspace=ws), out[1:2])
 
 
+@pytest.mark.parametrize("M,N,K,act,use_res", [(2885, 1024, 4096, 0, True), (577, 1024, 4096, 0, True), (577, 3072, 1024, 0, False),
+                                               (1154, 4096, 1024, 1, False), (700, 1000, 2048, 2, True)])
+def test_k_slices_for_small_grids(B, M, N, K, act, use_res):
+    """grids of fewer than 256 128^2 tiles with M > 512 (CLIP tower at 1..6 tiles) are cut along K into fp32 slabs + finalize:
+    same values as the whole-K tiles up to fp32 re-association (one bf16 ulp at most), the same bits from launch to launch."""
+    x = _rand((M, K), 1.0, 94).bfloat16()
+    w = (_rand((N, K), 1.0, 95) * 0.03).bfloat16()
+    bias = _rand((N,), 0.5, 96)
+    res = _rand((M, N), 1.0, 97).bfloat16() if use_res else None
+    whole = _whole_k(B, lambda: B.linear(x, w, bias, res, act, impl=0))
+    a = B.linear(x, w, bias, res, act, impl=0)
+    b = B.linear(x, w, bias, res, act, impl=0)
+    assert torch.equal(a, b)
+    ref = _ref_linear(x, w, bias, res, act)
+    check_close(f"K slices {M}x{N}x{K}", a, ref, BF16_MAX, BF16_L2)
+    assert float((a.float() - whole.float()).abs().max()) <= 2 ** -7 * float(whole.float().abs().max())
+
+
 def test_argmax_first_max(B):
     x = _rand((3, 32001), 1.0, 37)
     x[1, 777] = 50.0
@@ -364,6 +382,16 @@ GEMM256_SHAPES = [(2048, 6144, 4096), (2048, 4096, 14336), (2885, 4096, 1024), (
                   (3291, 1100, 256), (5000, 300, 128)]
 
 
+def _whole_k(B, fn):
+    """the 128^2 kernel with every tile summing its whole K in one workgroup (knob 26 = 0: no K slices for small grids), the
+    order the 256^2 kernel's whole tiles reproduce bit for bit"""
+    B.check(B.lib().vz_tune_set(26, 0))
+    try:
+        return fn()
+    finally:
+        B.check(B.lib().vz_tune_set(26, 1))
+
+
 @pytest.mark.parametrize("M,N,K", GEMM256_SHAPES)
 def test_gemm256_matches_gemm128(B, M, N, K):
     """The 256x256 kernel accumulates K in the same order as the 128x128 kernel, so with whole tiles its fp32 outputs
@@ -374,7 +402,7 @@ def test_gemm256_matches_gemm128(B, M, N, K):
     whoever arrives last)."""
     x = _rand((M, K), 1.0, 60).bfloat16()
     w = _rand((N, K), 0.05, 61).bfloat16()
-    ref = B.linear(x, w, out_fp32=True, impl=0)
+    ref = _whole_k(B, lambda: B.linear(x, w, out_fp32=True, impl=0))
     check_close(f"gemm128 ref {M}x{N}x{K}", ref, _ref_linear(x, w, None, None, 0), 1e-4, 1e-4)
     scale = float(ref.abs().max())
     try:
@@ -411,7 +439,7 @@ def test_gemm256_epilogues(B, act, M, N, K):
         out = B.linear(x, w, bias=bias, residual=res, act=act, impl=2)
     finally:
         B.check(B.lib().vz_tune_set(4, 1))
-    ref128 = B.linear(x, w, bias=bias, residual=res, act=act, impl=0)
+    ref128 = _whole_k(B, lambda: B.linear(x, w, bias=bias, residual=res, act=act, impl=0))
     check_close(f"gemm256 epilogue act{act}", out, _ref_linear(x, w, bias, res, act), BF16_MAX, BF16_L2)
     # stream-K re-associates the fp32 sum: a handful of outputs may round to the neighbouring bf16 value
     assert float((out.float() - ref128.float()).abs().max()) <= 2 ** -7 * float(ref128.float().abs().max())

@@ -725,6 +725,7 @@ def test_continuous_batching_matches_static_batches(env):
     from vz_hip import binding as B
     try:
         B.check(B.lib().vz_tune_set(4, 0))
+        B.check(B.lib().vz_tune_set(26, 0))        # and no tile-count-dependent K slices in the CLIP tower's small grids
         free_run = {i: static(i, None) for i in range(len(reqs))}
         # an eos that request 1 emits at its 8th token (mid-chunk with sync_every = 4) and that hits nobody's first token
         eos = free_run[1][7]
@@ -751,6 +752,7 @@ def test_continuous_batching_matches_static_batches(env):
             assert g1[0] == w[0] and len(g1) == len(w)           # (a 1-row step runs the GEMV: a near-tie may flip later tokens)
     finally:
         B.check(B.lib().vz_tune_set(4, 1))
+        B.check(B.lib().vz_tune_set(26, 1))
     del model
     torch.cuda.empty_cache()
 

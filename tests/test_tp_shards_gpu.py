@@ -126,12 +126,14 @@ def test_tile_data_parallel_encode_matches_unsharded():
     try:
         B.check(B.lib().vz_tune_set(1, 1))       # 128x128 kernel only
         B.check(B.lib().vz_tune_set(4, 0))
+        B.check(B.lib().vz_tune_set(26, 0))      # whole-K tiles whatever the tile count of a rank's share
         ref = model.encode_images(tiles, text, tile_sample=tile_sample)
         assert ref.shape == (T, cfg.qf_queries, cfg.hidden)
         assert torch.equal(tile_dp(), ref), "tile-data-parallel encode differs from the unsharded one"
     finally:
         B.check(B.lib().vz_tune_set(1, 0))
         B.check(B.lib().vz_tune_set(4, 1))
+        B.check(B.lib().vz_tune_set(26, 1))
     ref = model.encode_images(tiles, text, tile_sample=tile_sample)
     check_close("tile-DP vs unsharded (production dispatch)", tile_dp(), ref.float(), 0.25, 2e-2)
     # the C-ABI all-gather at tp_size 1 is a device copy into chunk 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """CLIP tower + Q-Former of the 5-tile bench workload, timed per stage with HIP events (one process, interleaved A/B of the
 knobs that only touch these stages: 23 = key split of the Q-Former cross-attention, 24 = split-K cap of its 160-row linears,
-25 = cross-attention K|V projections of all blocks as one GEMM).
+25 = cross-attention K|V projections of all blocks as one GEMM, 26 = K slices for tile GEMM grids that leave a CU one workgroup).
 
     python tools/bench_vision.py [tiles]"""
 import os
@@ -40,8 +40,11 @@ def main():
     ts = [0] * T
     print(f"tiles {T}", flush=True)
     for rnd in range(3):
-        clip = timed(lambda: eng.clip_fused_features(tiles))
-        row = [f"clip {clip:6.3f} ms"]
+        row = []
+        for v in (0, 1):
+            B.check(B.lib().vz_tune_set(26, v))
+            row.append(f"clip {timed(lambda: eng.clip_fused_features(tiles)):6.3f} ms ({'K slices for lone-workgroup grids' if v else 'whole-K tiles only'})")
+        B.check(B.lib().vz_tune_set(26, 1))
         for name, knobs in (("qformer base (no key split, 4 slices, K|V per block)", ((23, 1), (24, 4), (25, 0))), ("key split", ((23, 0), (24, 4), (25, 0))),
                             ("+ 8 slices", ((23, 0), (24, 8), (25, 0))), ("+ K|V of all blocks in one GEMM", ((23, 0), (24, 8), (25, 1)))):
             for k, v in knobs:

@@ -1306,6 +1306,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 23) { vz_set_attn_split(value); return VZ_OK; }
     if (knob == 24) { vz_set_splitk_cap(value); return VZ_OK; }
     if (knob == 25) { g_qf_kv_all = value; return VZ_OK; }
+    if (knob == 26) { vz_set_splitk_mid(value); return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }
     if (knob == 10) { if (value < 0 || value > 64) { vz_set_error("tune_set: decode attention splits must be 0..64"); return VZ_ERR_ARG; } g_attn_nsplit = value; return VZ_OK; }

@@ -17,6 +17,8 @@
 //
 // Semantics: hf:models/clip/modeling_clip.py:280-350, hf:models/mistral/modeling_mistral.py:35-48,
 // 122-178,450-453, torch.nn.MultiheadAttention projections (ref:vis_zephyr/model/multimodal_projector/builder.py:16-32).
+#include <algorithm>
+
 #include "vz_common.h"
 
 namespace {
@@ -370,6 +372,8 @@ static int g_gemm_choice = 0;
 void vz_set_gemm_choice(int v) { g_gemm_choice = v; }
 static int g_splitk_mode = 0;          // 0 auto, 1 never (A/B knob 3)
 void vz_set_splitk_mode(int v) { g_splitk_mode = v; }
+static int g_splitk_mid = 1;           // 1: K slices for grids of fewer than 256 tiles with M > 512 (A/B knob 26)
+void vz_set_splitk_mid(int v) { g_splitk_mid = v; }
 static int g_splitk_cap = 8;           // most K slices of a weight-streaming (M <= 512) product (A/B knob 24; 4 -> 8: Q-Former 3.87 -> 3.80 ms)
 void vz_set_splitk_cap(int v) { g_splitk_cap = v < 1 ? 1 : (v > 16 ? 16 : v); }
 // g_slab / g_slab_bytes (declared above): process-wide split-K workspace, 96 MiB up front, grown on demand outside captures
@@ -409,6 +413,15 @@ int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
     if (g_splitk_mode != 1 && a.M <= 512 && p.tiles_n < 128 && a.act != VZ_ACT_SWIGLU && (a.N & 3) == 0) {
         splitk = (256 + p.tiles_n - 1) / p.tiles_n;
         if (splitk > g_splitk_cap) splitk = g_splitk_cap;
+        while (splitk > 1 && nk / splitk < 8) --splitk;
+    }
+    // A grid that leaves the CUs a single workgroup each (or none) is cut along K until ~512 workgroups exist: a lone workgroup has nobody to
+    // hide its LDS / barrier latency behind (CLIP fc2 at 5 tiles: 184 tiles x K = 4096, 50 -> 31 us; CLIP tower 4.99 -> 4.54 ms at 5 tiles,
+    // 3.78 -> 2.8 at 1; tools/bench_vision.py).  Short K (1024: CLIP QKV / out) only pays on very small grids.  The factor follows the tile
+    // count, i.e. M: like the 128^2 / 256^2 choice it is not batch-invariant (knob 26 = 0 switches it off; the invariance tests do).
+    if (g_splitk_mid && splitk == 1 && a.M > 512 && a.act != VZ_ACT_SWIGLU && (a.N & 3) == 0 &&
+        ((tiles < 256 && nk >= 32) || (tiles <= 128 && nk >= 16))) {
+        splitk = std::min(4, 512 / tiles);
         while (splitk > 1 && nk / splitk < 8) --splitk;
     }
     if (a.splitk_hint > 0 && (a.N & 7) == 0) {       // decode batches (see LinearArgs.splitk_hint); SwiGLU pairs are formed in the finalize kernel

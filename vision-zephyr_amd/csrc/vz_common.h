@@ -192,7 +192,8 @@ int vz_gemm256_async_error(hipStream_t s, int* err, bool reset_only);
 int vz_gemm256_corrupt_tickets(hipStream_t s, int tr, int arrive, int ready);
 void vz_set_gemm_choice(int v);
 void vz_set_splitk_mode(int v);
-void vz_set_splitk_cap(int v);   // 0 auto, 1 force 128x128, 2 force 256x256
+void vz_set_splitk_cap(int v);
+void vz_set_splitk_mid(int v);   // 0 auto, 1 force 128x128, 2 force 256x256
 int vz_launch_linear(const LinearArgs& a, hipStream_t s);  // picks by M
 
 int vz_launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const float* w, const float* b, int rows,
