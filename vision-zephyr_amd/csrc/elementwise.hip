@@ -78,6 +78,64 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
     }
 }
 
+// The widths on the hot path (1024 CLIP, 4096 Zephyr / Q-Former, 5120 fused features) are whole 512-element chunks: without the
+// per-chunk bounds test every load of a row is issued before the first is used.  (The generic kernel above compiles to one
+// `global_load ; s_waitcnt vmcnt(0)` PER CHUNK inside its own exec branch - eight dependent round trips for a Zephyr row: 10.3 us for
+// 2048 x 4096, found in the ISA in the third session of round 2.)  Same arithmetic in the same order: bit-identical results.
+template <bool RMS, int NCH>
+__global__ __launch_bounds__(256) void norm_rows_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
+                                                        const float* __restrict__ w, const float* __restrict__ b, int rows, float eps) {
+    constexpr int cols = NCH * 512;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (size_t)row * ldx + lane * 8;
+    u16x8 t[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) t[c] = *(const u16x8*)(xr + c * 512);
+    // the scale vector does not wait for the row statistics: requested here, behind the row, it arrives under the reduction
+    const float* wr = w + lane * 8;
+    f32x4 w0[NCH], w1[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { w0[c] = *(const f32x4*)(wr + c * 512); w1[c] = *(const f32x4*)(wr + c * 512 + 4); }
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[c][j] = bf16_to_f32(t[c][j]); s += RMS ? v[c][j] * v[c][j] : v[c][j]; }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s / (float)cols + eps);
+    } else {
+        mean = s / (float)cols;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; q += d * d; }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / (float)cols + eps);
+    }
+    bf16_t* yr = y + (size_t)row * ldy + lane * 8;
+    const float* br = RMS ? nullptr : b + lane * 8;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+        if (!RMS) { b0 = *(const f32x4*)(br + c * 512); b1 = *(const f32x4*)(br + c * 512 + 4); }
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float wj = j < 4 ? w0[c][j] : w1[c][j - 4];
+            const float bj = j < 4 ? b0[j] : b1[j - 4];
+            const float r = RMS ? wj * (v[c][j] * rstd) : (v[c][j] - mean) * rstd * wj + bj;
+            o[j] = f32_to_bf16(r);
+        }
+        *(u16x8*)(yr + c * 512) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // RoPE (rotate-half, hf:models/mistral/modeling_mistral.py:51-81) on Q and K of a fused QKV row,
 // K/V appended to the cache [B][Hkv][max_ctx][D].  D = 128; 16 lanes x 16 bytes per (token, head).
@@ -146,8 +204,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const int* __restrict_
     const int kd = kind ? kind[row] : 0;
     const bf16_t* src = kd == 0 ? table + (size_t)idx[row] * cols : kd == 1 ? visual + (size_t)idx[row] * cols : nullptr;
     bf16_t* dst = out + (size_t)row * cols;
-    for (int k = lane * 8; k < cols; k += 512)
-        *(uint4*)(dst + k) = src ? *(const uint4*)(src + k) : make_uint4(0, 0, 0, 0);
+    // four 16-byte pieces requested before the first is stored (a load-store loop waits for every piece in turn)
+    for (int k0 = lane * 8; k0 < cols; k0 += 2048) {
+        uint4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = (src && k0 + u * 512 < cols) ? *(const uint4*)(src + k0 + u * 512) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u * 512 < cols) *(uint4*)(dst + k0 + u * 512) = t[u];
+    }
 }
 
 __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict__ src, long src_stride, bf16_t* __restrict__ dst,
@@ -155,8 +220,16 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    for (int k = lane * 8; k < cols; k += 512)
-        *(uint4*)(dst + (size_t)row * dst_stride + k) = *(const uint4*)(src + (size_t)row * src_stride + k);
+    const bf16_t* sr = src + (size_t)row * src_stride;
+    bf16_t* dr = dst + (size_t)row * dst_stride;
+    for (int k0 = lane * 8; k0 < cols; k0 += 2048) {
+        uint4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = k0 + u * 512 < cols ? *(const uint4*)(sr + k0 + u * 512) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u * 512 < cols) *(uint4*)(dr + k0 + u * 512) = t[u];
+    }
 }
 
 // The first len[z] tokens of KV-cache row src[z] -> row dst[z], every layer, K and V, every KV head in one launch
@@ -268,9 +341,28 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     const float* lr = logits + (size_t)row * cols;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int k = tid; k < cols; k += 1024) {
-        const float v = lr[k];
-        if (v > bv || (v == bv && k < bi)) { bv = v; bi = k; }
+    if ((cols & 3) == 0 && (((uintptr_t)lr) & 15) == 0) {
+        // 16 bytes per lane, eight requests in flight per thread (a 32000-wide row is one batch): the scalar loop below waits for
+        // every 4-byte load before it issues the next.  First maximum wins whatever the order of the comparisons.
+        const int n4 = cols >> 2;
+        for (int q0 = tid; q0 < n4; q0 += 8 * 1024) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = q0 + u * 1024 < n4 ? *(const f32x4*)(lr + (size_t)(q0 + u * 1024) * 4) : (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = t[u][j];
+                    const int k = (q0 + u * 1024) * 4 + j;
+                    if (v > bv || (v == bv && k < bi)) { bv = v; bi = k; }
+                }
+        }
+    } else {
+        for (int k = tid; k < cols; k += 1024) {
+            const float v = lr[k];
+            if (v > bv || (v == bv && k < bi)) { bv = v; bi = k; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -317,7 +409,10 @@ int vz_launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const floa
     VZ_CHECK_ARG(x && y && w && b && rows > 0, "layernorm: bad argument");
     VZ_CHECK_ARG(cols % 8 == 0 && cols <= NORM_MAX_CHUNKS * 512 && ldx % 8 == 0 && ldy % 8 == 0,
                  "layernorm: cols=%d must be a multiple of 8 and <= %d", cols, NORM_MAX_CHUNKS * 512);
-    hipLaunchKernelGGL(norm_kernel<false>, dim3(rows_grid(rows)), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, cols, eps);
+    if (cols == 1024) hipLaunchKernelGGL((norm_rows_kernel<false, 2>), dim3(rows_grid(rows)), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, eps);
+    else if (cols == 4096) hipLaunchKernelGGL((norm_rows_kernel<false, 8>), dim3(rows_grid(rows)), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, eps);
+    else if (cols == 5120) hipLaunchKernelGGL((norm_rows_kernel<false, 10>), dim3(rows_grid(rows)), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, eps);
+    else hipLaunchKernelGGL(norm_kernel<false>, dim3(rows_grid(rows)), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, cols, eps);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
@@ -327,8 +422,9 @@ int vz_launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const float*
     VZ_CHECK_ARG(x && y && w && rows > 0, "rmsnorm: bad argument");
     VZ_CHECK_ARG(cols % 8 == 0 && cols <= NORM_MAX_CHUNKS * 512 && ldx % 8 == 0 && ldy % 8 == 0,
                  "rmsnorm: cols=%d must be a multiple of 8 and <= %d", cols, NORM_MAX_CHUNKS * 512);
-    hipLaunchKernelGGL(norm_kernel<true>, dim3(rows_grid(rows)), dim3(256), 0, s, x, ldx, y, ldy, w, (const float*)nullptr,
-                       rows, cols, eps);
+    if (cols == 4096) hipLaunchKernelGGL((norm_rows_kernel<true, 8>), dim3(rows_grid(rows)), dim3(256), 0, s, x, ldx, y, ldy, w, (const float*)nullptr, rows, eps);
+    else hipLaunchKernelGGL(norm_kernel<true>, dim3(rows_grid(rows)), dim3(256), 0, s, x, ldx, y, ldy, w, (const float*)nullptr,
+                            rows, cols, eps);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
