@@ -363,7 +363,7 @@ int vz_init_gemm_kernels() {
         g_slab_bytes = (size_t)96 << 20;
     }
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-    { int r = vz_init_gemv_kernels(); if (r) return r; r = vz_init_gemm256_kernel(); if (r) return r; r = vz_init_skinny_kernels(); if (r) return r; r = vz_init_wide_kernels(); if (r) return r; }
+    { int r = vz_init_gemv_kernels(); if (r) return r; r = vz_init_gemm256_kernel(); if (r) return r; r = vz_init_skinny_kernels(); if (r) return r; r = vz_init_wide_kernels(); if (r) return r; r = vz_init_sampling_kernels(); if (r) return r; }
     done = true;
     return VZ_OK;
 }

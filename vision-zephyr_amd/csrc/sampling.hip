@@ -59,6 +59,18 @@ __device__ __forceinline__ float block_max(float v, SampleShared& sh) {
     return r;
 }
 
+// REG (cols <= 32768): the tempered row is staged ONCE in LDS (one batch of 32 global loads per thread) and all passes (maximum, the two
+// radix selects, the Gumbel race: up to 11 sweeps) read it from there; the loop form re-reads the row from L2 in every sweep, one
+// dependent 4-byte load at a time (the streamer path paid ~80 us per token for it).  Same values, same order-independent sums.
+// (Keeping the 32 values in registers spills at 1024 threads per workgroup: 128 VGPRs.)
+#define VZ_FOR_LOGITS(BODY)                                                                                          \
+    if (REG) {                                                                                                       \
+        _Pragma("unroll 8") for (int k = tid; k < cols; k += 1024) { const float x = lx[k]; BODY }                    \
+    } else {                                                                                                         \
+        for (int k = tid; k < cols; k += 1024) { const float x = lr[k] / temperature; BODY }                         \
+    }
+
+template <bool REG>
 __global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ logits, int cols, float temperature, int top_k,
                                                       float top_p, const unsigned* __restrict__ seed, const int* __restrict__ ctr,
                                                       int ctr_add, int* __restrict__ ids, int* __restrict__ pos, int* __restrict__ slot,
@@ -69,9 +81,19 @@ __global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ 
     const int row = blockIdx.x, tid = threadIdx.x;
     const float* lr = logits + (size_t)row * cols;
 
+    extern __shared__ float lx[];          // REG: cols floats
+    if (REG) {
+        float t[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { const int k = tid + i * 1024; t[i] = k < cols ? lr[k] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { const int k = tid + i * 1024; if (k < cols) lx[k] = t[i] / temperature; }
+        __syncthreads();
+    }
+
     // ---- 1. max of the tempered logits ----
     float m = -INFINITY;
-    for (int k = tid; k < cols; k += 1024) m = fmaxf(m, lr[k] / temperature);
+    VZ_FOR_LOGITS({ m = fmaxf(m, x); })
     m = block_max(m, sh);
 
     // ---- 2. top-k threshold key (0 = keep everything) ----
@@ -82,10 +104,10 @@ __global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ 
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) sh.hist[tid] = 0;
             __syncthreads();
-            for (int k = tid; k < cols; k += 1024) {
-                const unsigned key = fkey(lr[k] / temperature);
+            VZ_FOR_LOGITS({
+                const unsigned key = fkey(x);
                 if ((key & pmask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255], 1u);
-            }
+            })
             __syncthreads();
             if (tid == 0) {
                 unsigned long long cum = 0;
@@ -104,10 +126,9 @@ __global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ 
     unsigned pth = 0;
     if (top_p < 1.0f) {
         unsigned long long z = 0;
-        for (int k = tid; k < cols; k += 1024) {
-            const float x = lr[k] / temperature;
+        VZ_FOR_LOGITS({
             if (fkey(x) >= kth) z += (unsigned long long)(expf(x - m) * 1099511627776.0f);
-        }
+        })
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
         if ((tid & 63) == 0) sh.redm[tid >> 6] = z;
@@ -123,12 +144,11 @@ __global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ 
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) sh.mass[tid] = 0;
             __syncthreads();
-            for (int k = tid; k < cols; k += 1024) {
-                const float x = lr[k] / temperature;
+            VZ_FOR_LOGITS({
                 const unsigned key = fkey(x);
                 if (key >= kth && (key & pmask) == prefix)
                     atomicAdd(&sh.mass[(key >> shift) & 255], (unsigned long long)(expf(x - m) * 1099511627776.0f));
-            }
+            })
             __syncthreads();
             if (tid == 0) {
                 unsigned long long cum = below;
@@ -149,14 +169,14 @@ __global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ 
     const unsigned c2 = (unsigned)(ctr[0] + ctr_add);
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int k = tid; k < cols; k += 1024) {
-        const float x = lr[k] / temperature;
-        if (fkey(x) < keep) continue;
-        const unsigned w = philox_word0((unsigned)k, (unsigned)row, c2, 0x565au, k0, k1);
-        const float u = ((float)(w >> 9) + 0.5f) * 1.1920928955078125e-07f;       // 2^-23; exact in fp32, inside (0, 1)
-        const float v = x - logf(-logf(u));
-        if (v > bv || (v == bv && k < bi)) { bv = v; bi = k; }
-    }
+    VZ_FOR_LOGITS({
+        if (fkey(x) >= keep) {
+            const unsigned w = philox_word0((unsigned)k, (unsigned)row, c2, 0x565au, k0, k1);
+            const float u = ((float)(w >> 9) + 0.5f) * 1.1920928955078125e-07f;       // 2^-23; exact in fp32, inside (0, 1)
+            const float v = x - logf(-logf(u));
+            if (v > bv || (v == bv && k < bi)) { bv = v; bi = k; }
+        }
+    })
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(bv, o, 64);
@@ -180,13 +200,29 @@ __global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ 
 
 }  // namespace
 
+static bool g_sample_lds_ok = false;
+// dynamic-LDS limit of the staged kernel (128 KiB for a 32768-wide row), set once and never inside a stream capture
+int vz_init_sampling_kernels() {
+    static bool done = false;
+    if (done) return VZ_OK;
+    VZ_CHECK_HIP(hipFuncSetAttribute((const void*)sample_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * (int)sizeof(float)));
+    g_sample_lds_ok = true;
+    done = true;
+    return VZ_OK;
+}
+
 int vz_launch_sample(const float* logits, int rows, int cols, float temperature, int top_k, float top_p, const unsigned* seed,
                      const int* ctr, int ctr_add, int* ids, int* pos, int* slot, int* len, int* out_ids, int out_stride,
                      const int* step, int max_ctx, int rope_max, int* ring, int ring_n, hipStream_t s) {
     VZ_CHECK_ARG(logits && ids && seed && ctr && rows > 0 && cols > 0 && (!ring || ring_n > 0), "sample: bad argument");
     VZ_CHECK_ARG(temperature > 0.f && top_p > 0.f, "sample: temperature %g and top_p %g must be positive (temperature 0 = greedy: use argmax)", (double)temperature, (double)top_p);
-    hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(1024), 0, s, logits, cols, temperature, top_k, top_p, seed, ctr, ctr_add, ids, pos,
-                       slot, len, out_ids, out_stride, step, max_ctx, rope_max, ring, ring_n);
+    { int r = vz_init_sampling_kernels(); if (r) return r; }
+    if (cols <= 32768 && g_sample_lds_ok)
+        hipLaunchKernelGGL(sample_kernel<true>, dim3(rows), dim3(1024), (size_t)cols * sizeof(float), s, logits, cols, temperature, top_k, top_p, seed, ctr, ctr_add, ids, pos,
+                           slot, len, out_ids, out_stride, step, max_ctx, rope_max, ring, ring_n);
+    else
+        hipLaunchKernelGGL(sample_kernel<false>, dim3(rows), dim3(1024), 0, s, logits, cols, temperature, top_k, top_p, seed, ctr, ctr_add, ids, pos,
+                           slot, len, out_ids, out_stride, step, max_ctx, rope_max, ring, ring_n);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }

@@ -264,6 +264,7 @@ int vz_launch_sample(const float* logits, int rows, int cols, float temperature,
 // set dynamic-LDS limits of every kernel up front (never inside a stream capture)
 int vz_init_gemm_kernels();
 int vz_init_attention_kernels();
+int vz_init_sampling_kernels();
 int vz_launch_copy_rows(const bf16_t* src, long src_stride, bf16_t* dst, long dst_stride, int rows, int cols,
                         hipStream_t s);
 // KV-cache row moves (batched admissions of the continuous-batching loop): up to 16 (src row, dst row, tokens) triples per launch
