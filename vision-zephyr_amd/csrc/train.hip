@@ -157,6 +157,51 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     }
 }
 
+// cols = NCH * 512 (Zephyr: 4096): the row of x, dy and w in registers from one batch of 16-byte loads (the loop form above moves 2 bytes
+// per lane per access, twice over the row).  The per-lane partial sums run over other elements than the loop form's, so the fp32 sums
+// differ in the last bits from it - deterministically (same order every run).
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const bf16_t* __restrict__ dy,
+                                                               const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, long rows, float eps) {
+    constexpr int cols = NCH * 512;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const bf16_t* xr = x + row * cols + lane * 8;
+    const bf16_t* gr = dy + row * cols + lane * 8;
+    u16x8 xv[NCH], gv[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { xv[c] = *(const u16x8*)(xr + c * 512); gv[c] = *(const u16x8*)(gr + c * 512); }
+    float gw[NCH][8];
+    float ss = 0.f, gx = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const f32x4 w0 = *(const f32x4*)(w + c * 512 + lane * 8), w1 = *(const f32x4*)(w + c * 512 + lane * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xf = bf16_to_f32(xv[c][j]);
+            gw[c][j] = bf16_to_f32(gv[c][j]) * (j < 4 ? w0[j] : w1[j - 4]);
+            ss += xf * xf; gx += gw[c][j] * xf;
+        }
+    }
+    ss = wave_sum(ss); gx = wave_sum(gx);
+    const float r = rsqrtf(ss / cols + eps);
+    const float k = gx * r * r / cols;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        u16x8 dr = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (dres) dr = *(const u16x8*)(dres + row * cols + c * 512 + lane * 8);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = r * (gw[c][j] - bf16_to_f32(xv[c][j]) * k);
+            if (dres) v += bf16_to_f32(dr[j]);
+            o[j] = f32_to_bf16(v);
+        }
+        *(u16x8*)(dx + row * cols + c * 512 + lane * 8) = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // LayerNorm backward with parameter gradients (torch.nn.LayerNorm of the Q-Former, ref:...multimodal_projector/builder.py:14-27,68-70).
 //   xh = (x - mean) rstd, g = dy w:   dx = rstd (g - mean(g) - xh mean(g xh)) [+ dres];   dw = sum_rows dy xh;   db = sum_rows dy
@@ -480,7 +525,11 @@ int vz_launch_softmax_bwd(const bf16_t* P, int ldp, const float* dP, int lddp, b
 int vz_launch_rmsnorm_bwd(const bf16_t* x, const float* w, const bf16_t* dy, const bf16_t* dres, bf16_t* dx, long rows, int cols, float eps,
                           hipStream_t s) {
     VZ_CHECK_ARG(x && w && dy && dx && rows > 0 && cols > 0, "rmsnorm_bwd: bad argument");
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, x, w, dy, dres, dx, rows, cols, eps);
+    const bool aligned = (((uintptr_t)x | (uintptr_t)w | (uintptr_t)dy | (uintptr_t)dres | (uintptr_t)dx) & 15) == 0;
+    if (cols == 4096 && aligned)
+        hipLaunchKernelGGL((rmsnorm_bwd_rows_kernel<8>), dim3((int)((rows + 3) / 4)), dim3(256), 0, s, x, w, dy, dres, dx, rows, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, x, w, dy, dres, dx, rows, cols, eps);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
