@@ -83,7 +83,7 @@ if "stream" in sys.argv[1:]:
     res = {}
     for admit in (0, None):                   # one prefill per admission / the admissions of one sync share a prefill in the spare cache rows
         t0 = time.perf_counter()
-        done = dict(model.generate_stream(reqs, eos_token_id=None, rows=ROWS, sync_every=16, admit=admit))
+        done = dict(model.generate_stream(reqs, eos_token_id=-1, rows=ROWS, sync_every=16, admit=admit))   # -1: no token ends a sequence (None = the config's eos)
         torch.cuda.synchronize()
         res[admit] = time.perf_counter() - t0
         assert len(done) == n_items and all(len(done[i]) == budgets[i] for i in range(n_items))
