@@ -361,13 +361,20 @@ int vz_op_vip_point(void* d_image_u8, int h, int w, int x0, int y0, int x1, int 
 /* argmax over fp32 logits rows: ids int32 [rows] (first maximal index) */
 int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_stream stream);
 
-/* tuning hook for tools/bench_kernels.py: knob 0 = GEMV variant (0 = production choice, 1.. = alternatives
- * compiled into the library: rows per wave, chunks in flight, non-temporal loads), 1 = GEMM kernel choice,
- * 2 = prefill attention generation, 3 = split-K mode, 4 = 256^2 GEMM stream-K tail (1 = on, 0 = whole tiles only), 5 = stream-K skew in K-tiles, 6 = record 256^2 GEMM phase stamps,
- * 7 = route the collectives of a tp_size == 1 engine that holds a one-rank communicator through RCCL (self-test),
- * 9 = 2..16-row linears (1 = MFMA weight stream, 0 = GEMV / tile GEMM), 10 = context splits of the fused decode attention
- * (0 = engine default, 1..64), 13 = record role stamps of that launch, 16 = record stage stamps of the prefill attention kernel (vz_prof_attn_stamps), 15 = split-K factor of the K = 4096 projections on that route (default 8), 14 = rows from which a decode step's linears run on the 128^2 tile GEMM (default 25; 65 = never), 12 = one launch for QKV GEMV + attention + O GEMV of a batch-1 decode layer (1 = on; default 0), 11 = 256^2 GEMM workgroups wait for their epilogue stores before they end (experiment; 0 = off).
- * Process-wide. */
+/* A/B hook of the bench tools (process-wide; production values in brackets).  Knobs:
+ *   0  GEMV variant [0 = production choice; 1.. = alternatives compiled in: rows per wave, chunks in flight, non-temporal loads]
+ *   1  tile GEMM choice [0 = by grid size; 1 = always 128^2; 2 = always 256^2]      2  prefill attention generation [3]
+ *   3  split-K of M <= 512 linears [0 = auto; 1 = never]                             4  256^2 GEMM stream-K tail [1; 0 = whole tiles only; 2 = forced]
+ *   5  stream-K skew in K-tiles                                                     6  record 256^2 GEMM phase stamps (vz_prof_gemm_stamps)
+ *   7  route the collectives of a tp_size == 1 engine holding a one-rank communicator through RCCL (self-test; 2 = shape rehearsal)
+ *   9  2..16-row linears [1 = MFMA weight stream; 0 = GEMV / tile GEMM; 5 = ignore the tiled weight copies]
+ *  10  context splits of the fused decode attention [0 = engine default; 1..64]     11  256^2 GEMM workgroups wait for their stores (experiment) [0]
+ *  14  rows from which a decode step's linears take the 128^2 tile GEMM [29]          15  split-K factor of the K = 4096 projections on that route [8]
+ *  16  record stage stamps of the prefill attention kernel (vz_prof_attn_stamps)    19  gemm_wide.hip for 17..64-row gate|up / lm_head [1]
+ *  21  fp8 tile GEMM choice [0 = by grid size; 1 = 128^2; 2 = 256^2]                22  rows from which vz_engine_prefill_fp8 engines take the fp8 MFMA [768]
+ *  23  key split of few-row head_dim-512 attention [0 = every 96 keys; 1 = never; n >= 2 = n splits]
+ *  24  most K slices of an M <= 512 linear [8]                                      25  Q-Former cross-attention K|V of all blocks as one GEMM [1]
+ *  26  K slices for tile-GEMM grids that leave a CU one workgroup (M > 512, < 256 tiles) [1; 0 = whole-K tiles: batch-invariant] */
 int vz_tune_set(int knob, int value);
 
 /* per-kernel-class timing of the engine's launches with HIP events on the launch stream (bench.py's roofline
