@@ -135,3 +135,50 @@ def test_stream_argument_checks(stream):
     long = [{"input_ids": torch.ones(1, 500, dtype=torch.long), "max_new_tokens": 20}]
     with pytest.raises(ValueError):
         stream(ToyEngine(2), long, rows=1)                          # prompt + budget beyond max_ctx
+
+
+class ToyBatchEngine(ToyEngine):
+    """+ the static-batch surface of `_generate_batched`: one right-padded prefill, decode_begin with the first tokens"""
+
+    def prefill(self, embeds, seqlens, position_ids=None, all_logits=False, last_logits=True):
+        assert not all_logits and last_logits and embeds.shape[0] <= min(self.max_batch, 64)
+        self.dec_B = 0
+        return None, self.prefill_rows(0, embeds, seqlens)
+
+    def decode_begin(self, first_ids, next_pos, ctx_len):
+        self.dec_B = len(next_pos)
+        for b in range(self.dec_B):
+            assert len(self.rows[b]) == ctx_len[b] == next_pos[b]
+        self.cur = [int(t) for t in first_ids.tolist()] + [None] * (self.max_batch - self.dec_B)
+
+
+@pytest.mark.parametrize("n_seq,max_batch,sync_every,max_new", [(5, 8, 4, 24), (5, 2, 16, 24), (3, 4, 1, 9), (1, 1, 16, 5), (4, 4, 5, 1)])
+def test_static_batches_eos_and_padding_equal_solo_generation(monkeypatch, n_seq, max_batch, sync_every, max_new):
+    """`_generate_batched`: rows that emitted eos show the pad token from then on, the batch stops at the first step after which
+    every row is done, batches beyond the engine's rows run in parts - every row equals the sequence generated alone."""
+    from vis_zephyr.model import VisZephyrForCausalLM
+    from vz_hip import binding as B
+    monkeypatch.setattr(B, "argmax", lambda logits: logits.argmax(-1).to(torch.int32))
+    g = torch.Generator().manual_seed(n_seq * 10 + max_batch)
+    lens = torch.randint(2, 30, (n_seq,), generator=g).tolist()
+    prompts = [torch.randint(1, V, (L,), generator=g).tolist() for L in lens]
+    free = [solo(p, max_new, set()) for p in prompts]
+    eos = {free[0][min(3, max_new - 1)]} | ({free[-1][0]} if n_seq > 2 else set())     # one ends mid-way, one on its first token
+    S = max(lens)
+    emb = torch.zeros(n_seq, S, 1, dtype=torch.bfloat16)
+    for i, p in enumerate(prompts):
+        emb[i, :len(p), 0] = torch.tensor(p, dtype=torch.bfloat16)
+    eng = ToyBatchEngine(max_batch)
+    me = types.SimpleNamespace(engine=eng, device=torch.device("cpu"))
+    me._generate_batched = types.MethodType(VisZephyrForCausalLM._generate_batched, me)
+    PAD = 250
+    out = me._generate_batched(emb, lens, None, max_new, eos, PAD, sync_every)
+    want = [solo(p, max_new, eos) for p in prompts]
+    cap = min(max_batch, 64)
+    for i0 in range(0, n_seq, cap):              # each part stops when ITS rows are done; the rest of the row is padding
+        n_part = max(len(w) for w in want[i0:i0 + cap])
+        for i in range(i0, min(n_seq, i0 + cap)):
+            row = out[i].tolist()
+            assert row[:len(want[i])] == want[i], f"row {i}"
+            assert all(t == PAD for t in row[len(want[i]):]) and len(row) >= n_part
+    assert out.shape[1] == max(len(w) for w in want)
