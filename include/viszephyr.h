@@ -233,7 +233,11 @@ int vz_clip_fused_features(vz_engine* e, const void* d_images, int T, void* d_ou
  * d_feats bf16 [T,576,qf_kv_dim]; text conditioning per SAMPLE: d_text bf16 [n_samples,Lmax,hidden]
  * (rows past a sample's own length are the zero padding of ref:vis_zephyr/model/vis_zephyr_arch.py:178-189),
  * h_tile_sample[T] maps each tile to its sample (the reference expands the same text to every tile of a
- * sample, vis_zephyr_arch.py:174).  Lmax = 0: no text.  d_out bf16 [T,32,hidden]. */
+ * sample, vis_zephyr_arch.py:174).  Lmax = 0: no text.  d_out bf16 [T,32,hidden].
+ * Layout hint: when the blocks' "qf.<i>.ca_kv.w" (and ".b") tensors lie back to back in device memory, block-major - one
+ * [qf_blocks * 2 * hidden, qf_kv_dim] allocation registered slice by slice - the cross-attention K|V projections of all blocks run
+ * as ONE product (they read the same pre-normed features); any other placement computes them block by block, same results up to
+ * the stream-K tail's fp32 re-association. */
 int vz_qformer(vz_engine* e, const void* d_feats, int T, const void* d_text, int n_samples, int Lmax,
                const int* h_tile_sample, void* d_out, vz_stream stream);
 
