@@ -75,31 +75,60 @@ def pmc_traffic():
     return None
 
 
+BAND, BAND_ABS = 1.15, 5e-4     # tests/util.py: ||hip - reference|| <= BAND * ||bf16 oracle - reference|| + BAND_ABS
+
+
 def parity_check(model, ids, tiles, n_layers):
     """the request of this bench against the REFERENCE's own output for it (tests/golden/pin_l32_c2.npz: BASELINE configs[2] through
-    the imported reference on bf16-rounded weights, fp32 arithmetic - oracle/pin_against_reference.py --configs2): the first
-    token must be the reference's, the prefill's last-row logits must sit in the bf16 band, and the greedy ids are compared
-    until the first near-tie.  Runs outside the timed region."""
+    the imported reference on bf16-rounded weights, fp32 arithmetic - oracle/pin_against_reference.py --configs2) inside the
+    request's own bf16 band (pin_l32_c2_band.npz: the BF16-policy oracle on the same request, oracle/band_configs2.py) - the band
+    tests/test_depth32_gpu.py::test_configs2_against_the_reference_fixture_at_32_layers holds it to: the first token must be the
+    reference's, the prefill's last-row logits must sit inside 1.15 x the band, and where the free-running greedy ids leave the
+    reference's the reference's own top-2 gap at that step must be inside the step's measured error (a near-tie).  Runs outside
+    the timed region."""
     import numpy as np
     path = os.path.join(REPO, "tests", "golden", f"pin_l{n_layers}_c2.npz")
-    if not os.path.exists(path):
+    bpath = os.path.join(REPO, "tests", "golden", f"pin_l{n_layers}_c2_band.npz")
+    if not (os.path.exists(path) and os.path.exists(bpath)):
         return {"checked": False, "why": f"no fixture for {n_layers} layers"}
-    g = np.load(path)
+    g, gb = np.load(path), np.load(bpath)
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64)))  # noqa: E731
     eng = model.engine
     emb = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles])[4]
-    _, last = eng.prefill(emb, [emb.shape[1]])
-    lo = last[0].float().cpu().numpy().astype(np.float64)
-    ref = g["F16.logits.last"].astype(np.float64)
-    rel = float(np.linalg.norm(lo - ref) / np.linalg.norm(ref))
+    S = emb.shape[1]
+    _, last = eng.prefill(emb, [S])
+    lo = last[0].float().cpu().numpy()
+    e_last = rel(lo, g["F16.logits.last"])
+    band_last = rel(gb["C2.bf16_oracle.logits.last"], g["F16.logits.last"])
     n = int(g["F16.generate.ids"].shape[1])
     got = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n, eos_token_id=None, pad_token_id=2)[0].tolist()
     want = g["F16.generate.ids"][0].tolist()
     first_div = next((i for i in range(n) if got[i] != want[i]), -1)
-    ok = int(np.argmax(lo)) == want[0] == got[0] and rel <= 0.08
+    out = {"checked": True, "reference": "W16 (reference code, bf16-rounded weights, fp32 CPU arithmetic)", "first_id": got[0],
+           "last_row_logits_rel_l2": round(e_last, 5), "bf16_band_last_row": round(band_last, 5),
+           "tolerance": f"{BAND} x band + {BAND_ABS}", "greedy_ids_equal_until": first_div if first_div >= 0 else n, "of": n}
+    ok = int(np.argmax(lo)) == want[0] == got[0] and e_last <= BAND * band_last + BAND_ABS
+    if ok and first_div > 0:
+        # the logits of the step where the ids part: teacher-forced on the shared prefix (= the free-running logits of that step)
+        _, last = eng.prefill(emb, [S])
+        eng.decode_begin(torch.tensor(want[:1], dtype=torch.int32), [S], [S])
+        lg = None
+        for t in range(1, first_div + 1):
+            _, lg = eng.decode_steps(1, return_logits=True)
+            if t < first_div:
+                eng.decode_set_row(0, int(want[t]), S + t, S + t)
+        row = lg[0, 0].float().cpu().numpy()
+        ref_row = g["F16.step_logits.s64"][first_div]
+        e_step = rel(row[::64], ref_row)
+        gap = float(g["F16.step_top2.vals"][first_div, 0] - g["F16.step_top2.vals"][first_div, 1])
+        tol = 4.0 * e_step * float(np.sqrt((ref_row.astype(np.float64) ** 2).mean()))
+        out["near_tie_at_divergence"] = {"step": first_div, "reference_top2_gap": round(gap, 5), "tolerance_4x_step_error_x_rms": round(tol, 5),
+                                         "step_logits_rel_l2": round(e_step, 5),
+                                         "hip_took_the_reference_runner_up": bool(got[first_div] == int(g["F16.step_top2.ids"][first_div, 1]))}
+        ok = gap < tol and int(np.argmax(row)) == got[first_div]
     if not ok:
-        raise AssertionError(f"bench request deviates from the reference: first id {got[0]} vs {want[0]}, last-row logits rel-L2 {rel:.3e}")
-    return {"checked": True, "reference": "W16 (reference code, bf16-rounded weights, fp32 CPU arithmetic)", "first_id": got[0],
-            "last_row_logits_rel_l2": round(rel, 5), "greedy_ids_equal_until": first_div if first_div >= 0 else n, "of": n}
+        raise AssertionError(f"bench request deviates from the reference: {json.dumps(out)}")
+    return out
 
 
 class _Streamer:

@@ -94,6 +94,15 @@ int vz_op_tile_weights(const void* d_W, int N, int K, int ldw, void* d_Wt, vz_st
 int vz_op_linear_tiled(const void* d_A, int lda, const void* d_W, const void* d_Wt, int ldw, void* d_C, int ldc, int M, int N, int K,
                        const float* d_bias, const void* d_residual, int ldr, int act, int out_fp32, const float* d_norm_w,
                        float norm_eps, vz_stream stream);
+/* W8A16 form for 17..64 rows (ABI 10; SURVEY config 5: batched decode of the e4m3-weight engine - the reference's analogue is
+ * load_8bit / load_4bit, ref:vis_zephyr/model/builder.py:33-43, applied to every generate call of the eval loop,
+ * ref:vis_zephyr/eval/eval_vqa.py:176-199).  vz_op_tile_weights_fp8: e4m3 rows [N][ldw bytes] -> fragment order
+ * W8t[((G * K/64 + s) * 64 + 16 g + r) * 16 + i] = W8[16 G + r][64 s + 16 g + i] (one 1-KiB wave-instruction per 64-k step and 16-row
+ * group).  vz_op_linear_tiled_fp8: C = epi(A . (2^e_row * W8)^T) on that copy, bf16 activations, 17 <= M <= 64, N % 128 == 0,
+ * K % 1024 == 0; an engine registers the copy as "<e4m3 name>t" (dtype 2) and its 17..64-row decode steps stream it. */
+int vz_op_tile_weights_fp8(const void* d_W8, int N, int K, int ldw, void* d_W8t, vz_stream stream);
+int vz_op_linear_tiled_fp8(const void* d_A, int lda, const void* d_W8t, const float* d_wscale, void* d_C, int ldc, int M, int N, int K,
+                           const float* d_bias, const void* d_residual, int ldr, int act, int out_fp32, vz_stream stream);
 /* same contract, forcing one implementation (tests): impl 0 = 128^2 MFMA tile GEMM, 1 = GEMV (M <= 8), 2 = 256^2 tile GEMM,
  * 3 = MFMA weight stream for 2 <= M <= 64 (batched decode), 4 = the 128^2 tile GEMM with the finer split-K of the 17..64-row decode route */
 int vz_op_linear_impl(int impl, const void* d_A, int lda, const void* d_W, int ldw, void* d_C, int ldc,
@@ -275,8 +284,9 @@ int vz_llm_decode_sampling(vz_engine* e, int enable, float temperature, int top_
                            int first_counter);
 /* Streamer / stopping-criteria loop (ref:vis_zephyr/serve/cli.py:155-182 passes a TextStreamer and a KeywordsStoppingCriteria:
  * one host callback per token): every step's tail also writes its token to ring[row * ring_n + (draw counter mod ring_n)], a
- * device-visible HOST buffer, so the host keeps a step in flight and reads token t when the event behind step t fires. */
-int vz_llm_decode_ring(vz_engine* e, int* host_visible_ring, int ring_n);
+ * device-visible HOST buffer of ring_rows x ring_n ints, so the host keeps a step in flight and reads token t when the event behind
+ * step t fires.  vz_llm_decode_steps refuses a decode batch with more rows than the ring holds (ABI 10: ring_rows). */
+int vz_llm_decode_ring(vz_engine* e, int* host_visible_ring, int ring_n, int ring_rows);
 int vz_op_sample(const float* d_logits, int rows, int cols, float temperature, int top_k, float top_p, unsigned long long seed,
                  int counter, int* d_ids, vz_stream stream);
 /* how the last vz_llm_decode_steps ran: *graph = 1 when a captured hipGraph was replayed; *comm_in_graph = 1 when the RCCL

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
     from vz_hip import binding
     assert declared == set(binding.SYMBOLS), declared ^ set(binding.SYMBOLS)
     handle = binding.load_library(lib)          # raises AttributeError on a missing export
-    assert handle.vz_abi_version() == binding.ABI_VERSION == 9
+    assert handle.vz_abi_version() == binding.ABI_VERSION == 10
     assert handle.vz_target_arch() == b"gfx950"
     assert handle.vz_last_error() == b""
 

@@ -1,0 +1,203 @@
+"""BASELINE configs[3] and configs[4] at FULL size on one GPU (32 decoder layers, 64 rows), through size-independent properties -
+the CPU oracle needs hours at these sizes - plus the batched decode routes at the headline depth.  Two 32-layer engines are built
+for the whole module (bf16 and W8A16), every test reuses them.
+
+  configs[3]  Stage-1 pretrain shape (ref:script/pretrain.sh:32-45, ref:vis_zephyr/train/train.py:329-364 plain prompt
+              `<image>caption`): 64 samples x 5 anyres tiles (320 tiles), 40 ids each -> S = 199, labels in, loss + logits of every
+              position out (ref:vis_zephyr/model/language_model/vis_zephyr.py:51-98).  Properties: a sample's rows inside the
+              64-sample batch = the same sample alone (bf16 band); loss = HF's shifted cross-entropy of the returned logits.
+  configs[4]  VCR-eval batch inference (ref:vis_zephyr/eval/eval_vqa.py:71-114,176-199): 1920x804 frame -> ViP point overlay ->
+              device anyres (4 tiles) -> 64-row greedy generate of 128 tokens on the fp8-weight engine
+              (ref:vis_zephyr/model/builder.py:33-43 is the reference's quantised-weights switch).  Property: a request inside the
+              64-row batch = the same request alone, up to the first step whose two candidates are a near-tie in the request's own logits.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import band_tol, check_close, load_golden, record
+
+pytestmark = pytest.mark.gpu
+
+PINS = [[336, 672], [672, 336], [336, 1008], [1008, 336], [672, 672]]
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _hf(cfg):
+    from vis_zephyr.model import VisZephyrConfig
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=32, num_attention_heads=cfg.n_heads,
+                         num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+                         sliding_window=cfg.sliding_window, eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    hf.image_aspect_ratio = "anyres"
+    hf.mm_grid_pinpoints = str(PINS)
+    hf.mm_hidden_size = 5120
+    return hf
+
+
+@pytest.fixture(scope="module")
+def band32():
+    """the bf16 activation band at 32 layers, from the reference-made fixtures (as tests/test_depth32_gpu.py)"""
+    g = load_golden(32)
+    return _rel(g["E.bf16_oracle.step_logits.s64"], g["E.w16_on_fp32_ids.step_logits.s64"])
+
+
+@pytest.fixture(scope="module")
+def deep64():
+    from vz_hip import synth
+    from vis_zephyr.model import VisZephyrForCausalLM
+    cfg = synth.ArchConfig(n_layers=32)
+    model = VisZephyrForCausalLM.from_synthetic(_hf(cfg), seed=0, max_batch=64, max_ctx=256, max_tiles=80, max_text=48)
+    yield dict(cfg=cfg, model=model, synth=synth)
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.fixture(scope="module")
+def deep64_fp8():
+    from vz_hip import synth
+    from vis_zephyr.model import VisZephyrForCausalLM
+    cfg = synth.ArchConfig(n_layers=32)
+    model = VisZephyrForCausalLM.from_synthetic(_hf(cfg), seed=0, max_batch=64, max_ctx=200 + 4 * 32 + 128 + 16, max_tiles=64, max_text=208,
+                                                weight_fp8=True)
+    yield dict(cfg=cfg, model=model, synth=synth)
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_configs3_full_size_rows_vs_alone_and_loss(deep64, band32):
+    model, synth, cfg = deep64["model"], deep64["synth"], deep64["cfg"]
+    dev = model.device
+    Bn, n_tiles, n_ids = 64, 5, 40
+    S = n_ids - 1 + 32 * n_tiles
+    ids = torch.stack([synth.synth_ids(n_ids, cfg.vocab, image_pos=1, seed=100 + b) for b in range(Bn)]).to(dev)   # plain: <image> after BOS
+    labels = ids.clone()
+    labels[:, :2] = -100
+    mask = torch.ones_like(ids)
+    tiles = [synth.synth_tiles(n_tiles, seed=300 + b).to(dev).bfloat16() for b in range(Bn)]
+    _, pos, m2, _, emb, lab = model.prepare_inputs_labels_for_multimodal(ids, None, mask, None, labels, tiles)
+    assert tuple(emb.shape) == (Bn, S, cfg.hidden) and tuple(lab.shape) == (Bn, S)
+    assert int((lab != -100).sum()) == Bn * (n_ids - 2)            # the 160 visual rows and BOS carry no target
+    out = model(inputs_embeds=emb, attention_mask=m2, position_ids=pos, labels=lab)
+    logits = out.logits
+    assert tuple(logits.shape) == (Bn, S, cfg.vocab) and logits.dtype == torch.float32 and bool(torch.isfinite(logits).all())
+    # loss = HF's causal-LM loss of the returned logits (shift by one, ignore -100, mean over the valid targets), in float64
+    lg = logits[:, :-1].reshape(-1, cfg.vocab)
+    tg = lab[:, 1:].reshape(-1).to(dev)
+    valid = tg != -100
+    lse = torch.logsumexp(lg[valid].double(), dim=-1)
+    ce = float((lse - lg[valid].double().gather(1, tg[valid].view(-1, 1)).view(-1)).mean())
+    record("configs[3] full size loss", loss=float(out.loss), ce_of_returned_logits=ce, targets=int(valid.sum()))
+    assert abs(float(out.loss) - ce) <= 2e-5 * abs(ce), (float(out.loss), ce)
+    # a sample inside the batch of 64 = the sample alone (other chunk position, other GEMM row counts): bf16 band
+    worst = 0.0
+    for b in (0, 37, 63):
+        alone = model(input_ids=ids[b:b + 1], attention_mask=mask[b:b + 1], labels=labels[b:b + 1], images=[tiles[b]])
+        assert tuple(alone.logits.shape) == (1, S, cfg.vocab)
+        e = _rel(alone.logits[0].cpu().numpy(), logits[b].cpu().numpy())
+        worst = max(worst, e)
+        assert e <= band_tol(band32), f"sample {b}: alone vs inside the batch of {Bn}: rel-L2 {e:.3e}, bf16 band {band32:.3e}"
+        assert int(alone.logits[0, -1].argmax()) == int(logits[b, -1].argmax()) or e > 0
+    record("configs[3] full size rows vs alone", worst_rel_l2=worst, band=band32)
+    model.engine.check_async()
+
+
+def test_configs4_full_size_fp8_batch_vs_alone(deep64_fp8, band32):
+    from vz_hip.preprocess import AnyresPreprocessor, vip_point_box, vip_point_overlay
+    model, synth, cfg = deep64_fp8["model"], deep64_fp8["synth"], deep64_fp8["cfg"]
+    dev = model.device
+    Bn, n_new, L = 64, 128, 200
+    pre = AnyresPreprocessor(dev)
+    rng = np.random.default_rng(0)
+    tiles = []
+    for b in range(Bn):
+        frame = torch.from_numpy(rng.integers(0, 256, (804, 1920, 3), dtype=np.uint8)).to(dev).contiguous()    # host frame -> device
+        pts = [(float(rng.integers(100, 1800)), float(rng.integers(100, 700))) for _ in range(2)]
+        boxes = [vip_point_box(cx, cy, 1920, 804) for cx, cy in pts]
+        vip_point_overlay(frame, boxes, [(255, 0, 0, 255), (0, 128, 255, 200)])                               # ViP "point" prompts, in place
+        t = pre(frame, PINS)
+        assert tuple(t.shape) == (4, 3, 336, 336) and t.dtype == torch.bfloat16
+        tiles.append(t)
+    ids = torch.stack([synth.synth_ids(L, cfg.vocab, image_pos=5, seed=100 + b) for b in range(Bn)]).to(dev)
+    out = model.generate(input_ids=ids, images=tiles, images_size=[(1920, 804)] * Bn, do_sample=False, max_new_tokens=n_new,
+                         eos_token_id=None, pad_token_id=2)
+    assert tuple(out.shape) == (Bn, n_new)
+    model.engine.check_async()
+    report = []
+    for r in (0, 29, 63):
+        alone = model.generate(input_ids=ids[r:r + 1], images=[tiles[r]], images_size=[(1920, 804)], do_sample=False, max_new_tokens=n_new,
+                               eos_token_id=None, pad_token_id=2)[0].tolist()
+        got = out[r].tolist()
+        first = next((i for i in range(n_new) if got[i] != alone[i]), -1)
+        entry = dict(row=r, first_divergence=first)
+        if first >= 0:
+            # the request's own logits at that step (teacher-forced forward over prompt + the shared prefix): the two candidates
+            # must be a near-tie there - closer than a few bf16-band errors of that row
+            full_ids = torch.cat([ids[r], torch.tensor(alone[:first], dtype=ids.dtype, device=dev)]).unsqueeze(0)
+            row = model(input_ids=full_ids, images=[tiles[r]]).logits[0, -1].double().cpu()
+            gap = abs(float(row[alone[first]] - row[got[first]]))
+            tol = 4.0 * band_tol(band32) * float(row.pow(2).mean().sqrt())
+            entry.update(gap=gap, tolerance=tol)
+            assert gap < tol, f"row {r}: batch of {Bn} and the lone request part at step {first} with a logit gap {gap:.3e} (tolerance {tol:.3e})"
+        report.append(entry)
+    record("configs[4] full size fp8 batch vs alone", rows=report, tokens=n_new)
+    model.engine.check_async()
+
+
+@pytest.mark.parametrize("Bn", [12, 40, 64])
+def test_batched_decode_step_equals_prefill_at_32_layers(deep64, band32, Bn):
+    """The batched decode routes at the headline depth (BASELINE configs[3] / [4] run 64 rows per GPU): a 12-row step (persistent MFMA weight
+    stream on the fragment-tiled copies), a 40- and a 64-row step (tile GEMM with split-K for QKV / O / down, gemm_wide.hip for gate|up and
+    lm_head) on the 32-layer engine - under teacher forcing every row's decode-step logits sit in the bf16 band around its own prefill logits
+    at that position (ragged prompt lengths, per-row positions and cache slots), and nothing is NaN."""
+    model, cfg, synth = deep64["model"], deep64["cfg"], deep64["synth"]
+    eng = model.engine
+    lens = [24 + (5 * b) % 17 for b in range(Bn)]
+    Smax = max(lens) + 1
+    ids = torch.full((Bn, Smax), 2, dtype=torch.long)
+    for b in range(Bn):
+        ids[b, : lens[b] + 1] = synth.synth_ids(lens[b] + 1, cfg.vocab, image_pos=-1, seed=500 + b)
+    emb = eng.embed_tokens(ids)
+    full, _ = eng.prefill(emb, [l + 1 for l in lens], all_logits=True, last_logits=False)
+    eng.prefill(emb, lens, all_logits=False, last_logits=True)
+    eng.decode_begin(torch.tensor([int(ids[b, lens[b]]) for b in range(Bn)], dtype=torch.int32), lens, lens)
+    _, lg = eng.decode_steps(1, return_logits=True)
+    assert torch.isfinite(lg).all()
+    worst = 0.0
+    for b in range(Bn):
+        want = full[b, lens[b]].float().cpu()
+        worst = max(worst, _rel(lg[0, b].float().cpu().numpy(), want.numpy()))
+        check_close(f"depth32 B{Bn} row {b} decode step vs prefill row", lg[0, b], full[b, lens[b]], 8e-2, band_tol(band32))
+    record(f"depth32 batched decode step vs prefill, {Bn} rows", worst_rel_l2=worst)
+    eng.check_async()
+
+
+@pytest.mark.parametrize("Bn", [24, 64])
+def test_fp8_batched_decode_step_equals_prefill_at_32_layers(deep64_fp8, band32, Bn):
+    """The same property on the W8A16 engine's 17..64-row routes (round 3: the e4m3 fragment-tiled stream of gemm_wide.hip for every
+    projection): decode step = the row's own prefill logits on the identically quantised model (prefill runs bf16 MFMA on the dequantised
+    weights, so both sides see one model: ref:vis_zephyr/model/builder.py:33-43 quantises the linears for every call alike)."""
+    model, cfg, synth = deep64_fp8["model"], deep64_fp8["cfg"], deep64_fp8["synth"]
+    eng = model.engine
+    lens = [24 + (5 * b) % 17 for b in range(Bn)]
+    Smax = max(lens) + 1
+    ids = torch.full((Bn, Smax), 2, dtype=torch.long)
+    for b in range(Bn):
+        ids[b, : lens[b] + 1] = synth.synth_ids(lens[b] + 1, cfg.vocab, image_pos=-1, seed=500 + b)
+    emb = eng.embed_tokens(ids)
+    full, _ = eng.prefill(emb, [l + 1 for l in lens], all_logits=True, last_logits=False)
+    eng.prefill(emb, lens, all_logits=False, last_logits=True)
+    eng.decode_begin(torch.tensor([int(ids[b, lens[b]]) for b in range(Bn)], dtype=torch.int32), lens, lens)
+    _, lg = eng.decode_steps(1, return_logits=True)
+    assert torch.isfinite(lg).all()
+    worst = 0.0
+    for b in range(Bn):
+        worst = max(worst, _rel(lg[0, b].float().cpu().numpy(), full[b, lens[b]].float().cpu().numpy()))
+        check_close(f"depth32 fp8 B{Bn} row {b} decode step vs prefill row", lg[0, b], full[b, lens[b]], 8e-2, band_tol(band32))
+    record(f"depth32 fp8 batched decode step vs prefill, {Bn} rows", worst_rel_l2=worst)
+    eng.check_async()

@@ -881,6 +881,38 @@ def test_wide_tiled_gemm(B, M, N, K, act):
     assert torch.equal(head, out32[:lo])
 
 
+@pytest.mark.parametrize("M,N,K,act", [(64, 4096, 4096, 0), (24, 6144, 4096, 0), (64, 28672, 4096, 3), (33, 28672, 4096, 3), (64, 4096, 14336, 0),
+                                       (17, 4096, 14336, 0), (64, 32000, 4096, 0), (40, 1024, 2048, 1)])
+def test_wide_tiled_gemm_fp8(B, M, N, K, act):
+    """gemm_wide.hip's W8A16 stream (17..64-row decode steps of the e4m3-weight engine, round 3): the e4m3 fragment-tiled copy, widened to
+    bf16 in registers (exact), the row's 2^e on the finished sums - against the fp64 product with the DEQUANTISED weights (the
+    quantisation is exact data, so only fp32 accumulation and the output rounding remain), through bias / activation / SwiGLU / residual,
+    bf16 and fp32 outputs; K splits combined in split order: launches agree bit for bit; rows do not depend on the rows beside them; the
+    tiled copy holds exactly the row-major bytes (checked through the layout formula of include/viszephyr.h)."""
+    from vz_hip import quant
+    x = _rand((M, K), 1.0, 421).bfloat16()
+    w = (_rand((N, K), 1.0, 422) * K ** -0.5).bfloat16()
+    w8, ws = quant.quantize_rows(w)
+    wq = quant.dequantize_rows(w8, ws).bfloat16()
+    w8t = B.tile_weights_fp8(w8)
+    # layout: W8t[((G * S + s) * 64 + 16 g + r) * 16 + i] = W8[16 G + r][64 s + 16 g + i]
+    S = K // 64
+    back = w8t.view(N // 16, S, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(N, K)      # [G, s, g, r, i] -> [G, r, s, g, i]
+    assert torch.equal(back, w8)
+    n_out = N // 2 if act == 3 else N
+    bias = None if act == 3 else _rand((N,), 0.1, 423)
+    res = _rand((M, n_out), 0.5, 424).bfloat16()
+    out32 = B.linear_tiled_fp8(x, w8t, ws, N, bias=bias, residual=res, act=act, out_fp32=True)
+    check_close(f"wide tiled fp8 fp32 M{M} N{N} K{K} act{act}", out32, _ref_linear(x, wq, bias, res, act), 1e-4, 1e-4)
+    out = B.linear_tiled_fp8(x, w8t, ws, N, bias=bias, residual=res, act=act)
+    check_close(f"wide tiled fp8 bf16 M{M} N{N} K{K} act{act}", out, _ref_linear(x, wq, bias, res, act), BF16_MAX, BF16_L2)
+    for _ in range(3):
+        assert torch.equal(B.linear_tiled_fp8(x, w8t, ws, N, bias=bias, residual=res, act=act, out_fp32=True), out32)
+    lo = 17 if M <= 32 else 33
+    head = B.linear_tiled_fp8(x[:lo].contiguous(), w8t, ws, N, bias=bias, residual=res[:lo].contiguous(), act=act, out_fp32=True)
+    assert torch.equal(head, out32[:lo])
+
+
 def test_quant_rows_fp8_equals_host_quantiser(B):
     """the activation quantiser of the fp8 MFMA prefill = vz_hip.quant.quantize_rows (the weights' quantiser; the oracle's restatement is
     checked against the same function in tests/test_quant_cpu.py): scales and e4m3 bytes equal, exact powers of two and the 448 boundary included."""

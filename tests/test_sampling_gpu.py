@@ -61,7 +61,7 @@ def test_distribution_chi_square():
         n += rows
     assert cnt[pr == 0].sum() == 0, "a filtered token was drawn"
     big = pr * n >= 5
-    chi2 = float((((cnt - pr * n) ** 2) / (pr * n))[big].sum())
+    chi2 = float(((cnt[big] - pr[big] * n) ** 2 / (pr[big] * n)).sum())      # (mask first: the filtered tokens have pr = 0)
     dof = int(big.sum()) - 1
     assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
 

@@ -10,7 +10,7 @@ is an independent 2^-9 rounding, so the HIP path and the bf16-rounding oracle di
 about as much as either differs from the fp32 reference.  The stage tests therefore measure the bf16
 BAND itself and hold the HIP path to it:
     e_or  = ||oracle_bf16 - oracle_fp32|| / ||oracle_fp32||     (what ideal bf16 arithmetic costs)
-    e_hip = ||hip - oracle_fp32||        / ||oracle_fp32||      must be <= 1.6 * e_or + 5e-4
+    e_hip = ||hip - oracle_fp32||        / ||oracle_fp32||      must be <= band_tol(e_or)
     e_x   = ||hip - oracle_bf16||        / ||oracle_bf16||      must be <= 2.2 * e_or + 5e-4
 i.e. the GPU path may not be measurably worse than bf16 arithmetic done in fp32 on the CPU, and the
 fp32 golden vectors of the reference itself bound it in absolute terms (per-test constants).
@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import check_close, errs, load_golden, record, sub
+from util import band_tol, check_close, errs, load_golden, record, sub
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +57,7 @@ def band(name, hip, o_bf16, o_fp32):
     mx_x, e_x = errs(hip, o_bf16)
     record(name, e_oracle_bf16_vs_fp32=e_or, e_hip_vs_fp32=e_hip, e_hip_vs_bf16=e_x, max_hip_vs_fp32=mx_hip)
     assert torch.isfinite(hip.float()).all(), f"{name}: non-finite"
-    assert e_hip <= 1.6 * e_or + 5e-4, f"{name}: hip vs fp32 {e_hip:.3e} outside the bf16 band (oracle-bf16 vs fp32 {e_or:.3e})"
+    assert e_hip <= band_tol(e_or), f"{name}: hip vs fp32 {e_hip:.3e} outside the bf16 band (oracle-bf16 vs fp32 {e_or:.3e})"
     assert e_x <= 2.2 * e_or + 5e-4, f"{name}: hip vs oracle-bf16 {e_x:.3e} (band {e_or:.3e})"
 
 
@@ -124,10 +124,10 @@ def test_qformer(env):
     band("qformer no text", no_text, O.qformer(cfg, sd, feats, None, O.BF16), O.qformer(cfg, sd, feats, None, O.FP32))
 
 
-def test_splice_api_matches_oracle_batch(env):
-    """case B of the golden set: batch of 2, unequal lengths, padding mask, labels, position ids."""
-    O, cfg, sd, model, g = env["O"], env["cfg"], env["sd"], env["model"], env["gold"]
-    S = env["synth"]
+def _case_b(env):
+    """inputs of case B of the golden set: batch of 2, unequal lengths, padding mask, labels, position ids (built from seeds by
+    every test that needs them: no test reads another test's leftovers)"""
+    S, cfg = env["synth"], env["cfg"]
     tb0, tb1 = S.synth_tiles(2, seed=3), S.synth_tiles(1, seed=4)
     ids = torch.full((2, 20), 2, dtype=torch.long)
     ids[0] = S.synth_ids(20, cfg.vocab, image_pos=1, seed=5)
@@ -138,6 +138,14 @@ def test_splice_api_matches_oracle_batch(env):
     pos = torch.arange(20).unsqueeze(0).expand(2, -1).contiguous()
     lab = ids.clone()
     lab[ids == -200] = -100
+    return dict(ids=ids, mask=mask, pos=pos, lab=lab, tiles=[tb0, tb1])
+
+
+def test_splice_api_matches_oracle_batch(env):
+    """case B of the golden set: batch of 2, unequal lengths, padding mask, labels, position ids."""
+    O, cfg, sd, model, g = env["O"], env["cfg"], env["sd"], env["model"], env["gold"]
+    b = _case_b(env)
+    ids, mask, pos, lab, (tb0, tb1) = b["ids"], b["mask"], b["pos"], b["lab"], b["tiles"]
     r = model.prepare_inputs_labels_for_multimodal(ids, pos, mask, None, lab, [tb0, tb1], None)
     assert r[0] is None and r[3] is None
     assert np.array_equal(r[1].cpu().numpy(), g["B.position_ids"])
@@ -156,7 +164,6 @@ def test_splice_api_matches_oracle_batch(env):
     # early-outs of the reference (:148-149)
     assert model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, None)[4] is None
     assert model.prepare_inputs_labels_for_multimodal(ids[:, :1], None, None, None, None, [tb0, tb1])[4] is None
-    env["B"] = dict(ids=ids, mask=mask, pos=pos, lab=lab, tiles=[tb0, tb1], embeds=r[4], omask=r[2], opos=r[1])
 
 
 def test_forward_logits_case_a(env):
@@ -181,9 +188,7 @@ def test_forward_logits_case_a(env):
 
 def test_forward_batch_with_padding_and_loss(env):
     O, cfg, sd, model = env["O"], env["cfg"], env["sd"], env["model"]
-    b = env.get("B")
-    if b is None:
-        pytest.skip("depends on test_splice_api_matches_oracle_batch")
+    b = _case_b(env)
     out = model(input_ids=b["ids"], attention_mask=b["mask"], position_ids=b["pos"], labels=b["lab"], images=b["tiles"])
     emb = O.prepare_inputs_labels_for_multimodal(cfg, sd, b["ids"], b["pos"], b["mask"], None, b["lab"], b["tiles"], P=O.BF16)
     ref, _ = O.llm_forward(cfg, sd, emb[4], attention_mask=emb[2], position_ids=emb[1], P=O.BF16)
@@ -462,7 +467,7 @@ def test_fp8_weight_engine_matches_quantized_oracle(env):
     # attention) are two bf16 evaluation orders of the same network: they sit inside the same band the
     # oracle's own bf16-vs-fp32 distance defines, not inside a hand-picked constant
     e_or = errs(lo_bf, lo_32)[1]
-    check_close("fp8 decode step vs prefill", lg[0, 0], full[0, S0], 3e-2, 1.6 * e_or + 5e-4)
+    check_close("fp8 decode step vs prefill", lg[0, 0], full[0, S0], 3e-2, band_tol(e_or))
     # greedy generation against the quantised-weight oracle
     n_new = 6
     got = model.generate(input_ids=ids.unsqueeze(0), do_sample=False, max_new_tokens=n_new, eos_token_id=None, pad_token_id=2)
@@ -488,7 +493,7 @@ def test_fp8_weight_engine_matches_quantized_oracle(env):
     eng.prefill(emb2[:, :S0].contiguous(), [S0], all_logits=False, last_logits=True)
     eng.decode_begin(ids[S0:S0 + 1].to(torch.int32), [S0], [S0])
     _, lg2 = eng.decode_steps(1, return_logits=True)
-    check_close("fp8 decode step vs prefill after a second load", lg2[0, 0], full2[0, S0], 3e-2, 1.6 * e_or + 5e-4)
+    check_close("fp8 decode step vs prefill after a second load", lg2[0, 0], full2[0, S0], 3e-2, band_tol(e_or))
     # resize_token_embeddings on the fp8 engine: lm_head8 / lm_heads are rebuilt at the new size (finalize used to fail on the stale ones)
     model.resize_token_embeddings(cfg.vocab + 1)
     assert eng.w["llm.lm_head8"].shape[0] == cfg.vocab + 1 and eng.w["llm.lm_heads"].shape[0] == cfg.vocab + 1

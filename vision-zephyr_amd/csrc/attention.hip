@@ -798,8 +798,8 @@ void vz_set_attn_version(int v) { g_attn_version = v; }
 void vz_set_attn_split(int v) { g_attn_split = v; }
 
 int vz_init_attention_kernels() {
-    static bool done = false;
-    if (done) return VZ_OK;
+    static VzDeviceOnce once;
+    if (!vz_device_first(once)) return VZ_OK;
     int r;
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<64, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 * 2 + 64 * 2)));
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)flash_attn2_kernel<64, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 * 2 + 64 * 2)));
@@ -812,7 +812,6 @@ int vz_init_attention_kernels() {
     if ((r = set_flash_attr<64, 64>())) return r;
     if ((r = set_flash_attr<128, 64>())) return r;
     if ((r = set_flash_attr<512, 32>())) return r;
-    done = true;
     return VZ_OK;
 }
 

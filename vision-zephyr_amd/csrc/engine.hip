@@ -38,7 +38,7 @@ void vz_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vz_last_error(void) { return g_err; }
-extern "C" int vz_abi_version(void) { return 9; }
+extern "C" int vz_abi_version(void) { return 10; }
 extern "C" const char* vz_target_arch(void) { return "gfx950"; }
 
 // ------------------------------------------------------------------------------------------------
@@ -115,6 +115,18 @@ extern "C" int vz_op_linear_tiled(const void* A, int lda, const void* W, const v
     if (M >= 17 && vz_wide_ok(a)) return vz_launch_wide(a, (hipStream_t)s);          // 17..64 rows: gemm_wide.hip
     VZ_CHECK_ARG(g_skinny_mode && vz_skinny_ok(a), "linear_tiled: the MFMA weight stream takes 2 <= M <= 64 (fused norm: <= 16), K %% 64 == 0 (M=%d K=%d)", M, K);
     return vz_launch_skinny(a, (hipStream_t)s);
+}
+extern "C" int vz_op_tile_weights_fp8(const void* W8, int N, int K, int ldw, void* W8t, vz_stream s) {
+    return vz_launch_tile_weights_fp8((const unsigned char*)W8, N, K, ldw, (unsigned char*)W8t, (hipStream_t)s);
+}
+// 17..64 rows on the e4m3 fragment-tiled copy (gemm_wide.hip's W8A16 stream): C = epi((A . dequant(W8)^T)), bf16 activations
+extern "C" int vz_op_linear_tiled_fp8(const void* A, int lda, const void* W8t, const float* wscale, void* C, int ldc, int M, int N, int K,
+                                      const float* bias, const void* residual, int ldr, int act, int out_fp32, vz_stream s) {
+    VZ_CHECK_ARG(W8t && wscale && (N & 127) == 0, "linear_tiled_fp8: needs the tiled e4m3 copy + row scales of a dense [N, K] weight with N %% 128 == 0");
+    LinearArgs a = mk_linear(A, lda, W8t, K, C, ldc, M, N, K, bias, residual, ldr, act, out_fp32);      // (W is unused on this route: any aligned pointer)
+    a.W8t = (const unsigned char*)W8t; a.wscale = wscale;
+    VZ_CHECK_ARG(vz_wide_ok(a), "linear_tiled_fp8: needs 17 <= M <= 64, K %% 1024 == 0 (M=%d N=%d K=%d)", M, N, K);
+    return vz_launch_wide(a, (hipStream_t)s);
 }
 extern "C" int vz_op_linear_impl(int impl, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N,
                                  int K, const float* bias, const void* residual, int ldr, int act, int out_fp32,
@@ -213,6 +225,7 @@ struct vz_engine {
     // row-major bf16 weight -> its fragment-tiled copy (registered as "<name>t", same element count): the 2..64-row decode
     // linears stream the tiled copy (gemm_skinny.hip); rebuilt whenever the registry changes
     std::unordered_map<const void*, const bf16_t*> tiled; bool tiled_dirty = true;
+    std::unordered_map<const void*, const unsigned char*> tiled8;      // e4m3 copy "<name>8" / "<name>.w8" -> its fragment-tiled copy "<..>t" (dtype 2)
     bool finalized = false;
     // rope
     const float* cosT = nullptr; const float* sinT = nullptr; int rope_max = 0;
@@ -231,7 +244,7 @@ struct vz_engine {
     std::vector<int> h_len, h_pos; std::vector<char> h_parked;
     // sampling tail (vz_llm_decode_sampling): off = greedy argmax
     int samp_on = 0, samp_top_k = 0, samp_ctr0 = 0; float samp_temp = 1.f, samp_top_p = 1.f; unsigned samp_seed[2] = {0, 0};
-    int* ring = nullptr; int ring_n = 0;   // host-visible token ring of the streamer path (vz_llm_decode_ring)
+    int* ring = nullptr; int ring_n = 0, ring_rows = 0;   // host-visible token ring of the streamer path (vz_llm_decode_ring): [ring_rows][ring_n]
     hipStream_t last_stream = nullptr;   // stream of the last stage call (vz_engine_async_error resets that stream's stream-K tickets)
     int dec_nsplit = 1;          // context splits of the decode attention for the steps being launched
     float* d_logits = nullptr;   // [max_batch, vocab] fp32
@@ -304,16 +317,38 @@ static int linear(vz_engine* e, int klass_hint, const bf16_t* A, int lda, const 
     a.norm_w = norm_w; a.norm_eps = norm_eps; a.err = e->d_ferr; e->last_stream = s;
     if (klass_hint == 1 && M >= 2 && ldw == K) {       // decode step: the fragment-tiled copy of this weight, if the caller registered one
         if (e->tiled_dirty) {
-            e->tiled.clear();
+            e->tiled.clear(); e->tiled8.clear();
             for (const auto& kv : e->w) {
-                if (kv.second.dtype != 0 || kv.first.empty() || kv.first.back() != 't') continue;
+                if ((kv.second.dtype != 0 && kv.second.dtype != 2) || kv.first.empty() || kv.first.back() != 't') continue;
                 auto base = e->w.find(kv.first.substr(0, kv.first.size() - 1));
-                if (base != e->w.end() && base->second.dtype == 0 && base->second.n == kv.second.n) e->tiled[base->second.p] = (const bf16_t*)kv.second.p;
+                if (base == e->w.end() || base->second.dtype != kv.second.dtype || base->second.n != kv.second.n) continue;
+                if (kv.second.dtype == 0) e->tiled[base->second.p] = (const bf16_t*)kv.second.p;
+                else e->tiled8[base->second.p] = (const unsigned char*)kv.second.p;
             }
             e->tiled_dirty = false;
         }
         auto it = e->tiled.find((const void*)W);
         if (it != e->tiled.end()) a.Wt = it->second;
+        if (W8 && ws && M >= 17 && M <= 64) {
+            // 17..64-row step of an e4m3-weight engine: every projection streams the e4m3 fragment-tiled copy (gemm_wide.hip, round 3) -
+            // half the bytes of the bf16 routes these row counts took before (the row-major e4m3 stream of gemm_skinny.hip was slower than
+            // bf16 at 17..32 rows and unused beyond).  The RMSNorm runs as its own launch.
+            auto it8 = e->tiled8.find((const void*)W8);
+            if (it8 != e->tiled8.end()) {
+                LinearArgs t = a;
+                t.W8t = it8->second; t.wscale = ws; t.W8 = nullptr; t.Wt = nullptr; t.wide_ok = true;
+                if (norm_w) { t.A = e->d_xnorm; t.lda = K; t.norm_w = nullptr; }
+                if (vz_wide_ok(t)) {
+                    if (norm_w) {
+                        ProfScope ps(e, K_NORM, s);
+                        int r = vz_launch_rmsnorm(A, lda, e->d_xnorm, K, norm_w, M, K, norm_eps, s);
+                        if (r) return r;
+                    }
+                    ProfScope ps(e, K_GEMV, s);
+                    return vz_launch_wide(t, s);
+                }
+            }
+        }
     }
     a.wide_ok = klass_hint == 1;          // 1 = decode step: rows are independent sequences
     if (W8 && ws) {                       // e4m3 copy of the same weights: only the weight-stream kernels (M <= 32) take it
@@ -1058,8 +1093,14 @@ extern "C" int vz_llm_kv_move_rows(vz_engine* e, int n, const int* h_src, const 
     NEED_READY();
     VZ_CHECK_ARG(n >= 1 && h_src && h_dst && h_len, "kv_move_rows: bad argument");
     const vz_config& c = e->c;
-    for (int i = 0; i < n; ++i)
-        VZ_CHECK_ARG(e->dec_B == 0 || h_src[i] >= e->dec_B || e->h_parked[h_src[i]], "kv_move_rows: source row %d belongs to the running decode batch", h_src[i]);
+    for (int i = 0; i < n; ++i) {
+        VZ_CHECK_ARG(h_src[i] >= 0 && h_src[i] < c.max_batch && h_dst[i] >= 0 && h_dst[i] < c.max_batch && h_len[i] >= 0 && h_len[i] <= c.max_ctx,
+                     "kv_move_rows: move %d (row %d -> row %d, %d positions) outside the cache (max_batch %d, max_ctx %d)", i, h_src[i], h_dst[i], h_len[i], c.max_batch, c.max_ctx);
+        // a row of the running decode batch may only be read or overwritten while it is parked: moving into a live row would replace
+        // the keys that row keeps attending to
+        VZ_CHECK_ARG(h_src[i] >= e->dec_B || e->h_parked[h_src[i]], "kv_move_rows: source row %d belongs to the running decode batch", h_src[i]);
+        VZ_CHECK_ARG(h_dst[i] >= e->dec_B || e->h_parked[h_dst[i]], "kv_move_rows: destination row %d is a live row of the running decode batch (park it first)", h_dst[i]);
+    }
     for (int i0 = 0; i0 < n; i0 += 16) {
         KvMoves mv;
         mv.n = std::min(16, n - i0);
@@ -1145,18 +1186,21 @@ extern "C" int vz_llm_decode_sampling(vz_engine* e, int enable, float temperatur
 // Streamer / stopping-criteria path: besides d_out_ids every step's tail also writes its token to ring[row * ring_n + (draw
 // counter mod ring_n)], a DEVICE-VISIBLE HOST buffer (hipHostMalloc / pinned), so the host can keep a step or two in flight and
 // read token t as soon as the event recorded behind step t fires, without a device-to-host copy per token.  NULL = off.
-extern "C" int vz_llm_decode_ring(vz_engine* e, int* ring, int ring_n) {
-    VZ_CHECK_ARG(e && (!ring || ring_n >= 2), "decode_ring: ring_n >= 2 expected");
-    e->ring = ring; e->ring_n = ring ? ring_n : 0;
+extern "C" int vz_llm_decode_ring(vz_engine* e, int* ring, int ring_n, int ring_rows) {
+    VZ_CHECK_ARG(e && (!ring || (ring_n >= 2 && ring_rows >= 1)), "decode_ring: ring_n >= 2 slots and ring_rows >= 1 rows expected");
+    e->ring = ring; e->ring_n = ring ? ring_n : 0; e->ring_rows = ring ? ring_rows : 0;
     return VZ_OK;
 }
 
 // one draw per row of fp32 logits [rows, cols] with the same kernel (the first token of a sampled generation; tests)
 extern "C" int vz_op_sample(const float* d_logits, int rows, int cols, float temperature, int top_k, float top_p,
                             unsigned long long seed, int counter, int* d_ids, vz_stream stream) {
-    static thread_local int* d_scratch = nullptr;        // [counter, seed lo, seed hi, -]
+    // [counter, seed lo, seed hi, -] in this (device, stream)'s own scratch words: launches on other streams or devices have theirs
     hipStream_t s = (hipStream_t)stream;
-    if (!d_scratch) VZ_CHECK_HIP(hipMalloc((void**)&d_scratch, 4 * sizeof(int)));
+    VZ_CHECK_ARG(d_logits && d_ids && rows >= 1 && cols >= 1, "sample: bad argument");
+    int* d_scratch = nullptr;
+    { void* p = nullptr; size_t have = 0; int r = vz_stream_ws(4, s, 64, true, &p, &have); if (r) return r;
+      VZ_CHECK_ARG(p && have >= 16, "sample: first use of a stream inside a capture (call it once before capturing)"); d_scratch = (int*)p; }
     VZ_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)d_scratch, counter, 1, s));
     VZ_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(d_scratch + 1), (int)(unsigned)seed, 1, s));
     VZ_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(d_scratch + 2), (int)(unsigned)(seed >> 32), 1, s));
@@ -1171,6 +1215,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     VZ_CHECK_ARG(e->dec_B >= 1, "decode_steps: call vz_llm_decode_begin first");
     VZ_CHECK_ARG(n >= 1 && d_out_ids, "decode_steps: bad argument");
     const int B = e->dec_B;
+    VZ_CHECK_ARG(!e->ring || B <= e->ring_rows, "decode_steps: the token ring holds %d rows, the decode batch has %d", e->ring_rows, B);
     const size_t need = ((size_t)B * (3 * c.hidden + (c.n_heads + 2 * c.n_kv_heads) * c.head_dim + c.inter)) * 2 + 8192;   // upper bound (tp = 1 sizes)
     RC(ensure_arena(e, need));
     // tensor-parallel steps: the RCCL all-reduces / all-gather are captured with the kernels (one graph launch per token instead of
@@ -1221,6 +1266,11 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
         if (e->dec_graph) { hipGraphExecDestroy(e->dec_graph); e->dec_graph = nullptr; }
         hipGraph_t graph;
         if (!e->cap_stream) VZ_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+        if (B >= 17) {     // split-K scratch of the capture stream (128^2 tile route, gemm_wide K splits): never allocated inside a capture
+            void* p = nullptr; size_t have = 0;
+            RC(vz_stream_ws(0, e->cap_stream, (size_t)96 << 20, false, &p, &have));
+            RC(vz_wide_reserve(e->cap_stream));
+        }
         VZ_CHECK_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
         int r = decode_step_launch(e, d_out_ids, n, nullptr, e->cap_stream);
         graph = nullptr;
@@ -1306,6 +1356,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 23) { vz_set_attn_split(value); return VZ_OK; }
     if (knob == 24) { vz_set_splitk_cap(value); return VZ_OK; }
     if (knob == 25) { g_qf_kv_all = value; return VZ_OK; }
+    if (knob == 27) { g_wide_fp8_splits = value; return VZ_OK; }
     if (knob == 26) { vz_set_splitk_mid(value); return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }

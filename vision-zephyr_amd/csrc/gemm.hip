@@ -19,6 +19,11 @@
 // 122-178,450-453, torch.nn.MultiheadAttention projections (ref:vis_zephyr/model/multimodal_projector/builder.py:16-32).
 #include <algorithm>
 
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "vz_common.h"
 
 namespace {
@@ -387,18 +392,55 @@ int vz_linear_check_common(const LinearArgs& a) {
     return VZ_OK;
 }
 
-static float* g_slab;
-static size_t g_slab_bytes;
-int vz_init_gemm_kernels() {
-    static bool done = false;
-    if (done) return VZ_OK;
-    if (!g_slab) {   // split-K workspace for every shape a captured decode step can reach (M <= 8) and the Q-Former's (M <= 512)
-        VZ_CHECK_HIP(hipMalloc((void**)&g_slab, (size_t)96 << 20));
-        g_slab_bytes = (size_t)96 << 20;
+// ---- per-(device, stream) scratch ----
+// Split-K slabs and arrival tickets are written by one launch and read by the next: launches that share them must be ordered.  They
+// therefore exist per (kind, device, stream) - two engines, two streams or two devices in one process (the reference's API server
+// runs generate() in a thread per request, ref:vis_zephyr/serve/api.py:148-184) never meet on one slab - like the stream-K state of
+// gemm256.hip.  Nothing is allocated inside a stream capture: a capturing launcher that finds no scratch gets nullptr and takes its
+// whole-K route; vz_llm_decode_steps reserves the scratch of its capture stream before it captures.
+namespace {
+struct StreamWs { void* p = nullptr; size_t bytes = 0; };
+std::mutex g_ws_mu;
+std::map<std::tuple<int, int, hipStream_t>, StreamWs> g_ws;
+}  // namespace
+
+int vz_stream_ws(int kind, hipStream_t s, size_t min_bytes, bool zero, void** out, size_t* out_bytes) {
+    int dev = 0;
+    VZ_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    StreamWs& w = g_ws[std::make_tuple(kind, dev, s)];
+    if (w.bytes < min_bytes) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) {
+            if (w.p) { VZ_CHECK_HIP(hipDeviceSynchronize()); VZ_CHECK_HIP(hipFree(w.p)); w.p = nullptr; w.bytes = 0; }
+            VZ_CHECK_HIP(hipMalloc(&w.p, min_bytes));
+            if (zero) VZ_CHECK_HIP(hipMemset(w.p, 0, min_bytes));
+            w.bytes = min_bytes;
+        }
     }
+    *out = w.p;                       // (inside a capture: whatever exists, possibly nothing / too small - the caller checks *out_bytes)
+    if (out_bytes) *out_bytes = w.bytes;
+    return VZ_OK;
+}
+
+bool vz_device_first(VzDeviceOnce& o) {
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) dev = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (o.seen[dev >> 6] & bit) return false;
+    o.seen[dev >> 6] |= bit;
+    return true;
+}
+
+constexpr size_t SLAB_DEFAULT = (size_t)96 << 20;    // every split-K shape a captured decode step reaches (64 rows x 8 slices of the lm_head) and the Q-Former's (M <= 512)
+int vz_init_gemm_kernels() {
+    static VzDeviceOnce once;                        // per device: hipFuncSetAttribute is a per-device setting
+    if (!vz_device_first(once)) return VZ_OK;
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
     { int r = vz_init_gemv_kernels(); if (r) return r; r = vz_init_gemm256_kernel(); if (r) return r; r = vz_init_skinny_kernels(); if (r) return r; r = vz_init_wide_kernels(); if (r) return r; r = vz_init_sampling_kernels(); if (r) return r; }
-    done = true;
     return VZ_OK;
 }
 
@@ -410,7 +452,6 @@ static int g_splitk_mid = 1;           // 1: K slices for grids of fewer than 25
 void vz_set_splitk_mid(int v) { g_splitk_mid = v; }
 static int g_splitk_cap = 8;           // most K slices of a weight-streaming (M <= 512) product (A/B knob 24; 4 -> 8: Q-Former 3.87 -> 3.80 ms)
 void vz_set_splitk_cap(int v) { g_splitk_cap = v < 1 ? 1 : (v > 16 ? 16 : v); }
-// g_slab / g_slab_bytes (declared above): process-wide split-K workspace, 96 MiB up front, grown on demand outside captures
 
 // Tile choice: the 256x256 8-phase kernel runs one workgroup per CU, so it needs enough 256^2 tiles to fill the
 // 256 CUs several times over (>= 512 tiles: measured cross-over on MI355X, tools/bench_kernels.py); smaller grids keep the
@@ -461,18 +502,17 @@ int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
     if (a.splitk_hint > 0 && (a.N & 7) == 0) {       // decode batches (see LinearArgs.splitk_hint); SwiGLU pairs are formed in the finalize kernel
         splitk = a.splitk_hint;
         while (splitk > 1 && nk / splitk < 4) --splitk;
-        // this route runs inside the captured decode graph: the slab never grows there (96 MiB up front covers 64 rows x 8 slices of the lm_head)
-        while (splitk > 1 && (size_t)splitk * a.M * a.N * sizeof(float) > g_slab_bytes) --splitk;
     }
     p.splitk = splitk; p.slab = nullptr; p.n_inner = 0; p.a_div = p.w_div = 1; p.a_so = p.a_si = p.w_so = p.w_si = p.c_so = p.c_si = 0;
     if (splitk > 1) {
-        const size_t need = (size_t)splitk * a.M * a.N * sizeof(float);
-        if (need > g_slab_bytes) {
-            if (g_slab) { VZ_CHECK_HIP(hipDeviceSynchronize()); VZ_CHECK_HIP(hipFree(g_slab)); g_slab = nullptr; g_slab_bytes = 0; }
-            VZ_CHECK_HIP(hipMalloc((void**)&g_slab, need));
-            g_slab_bytes = need;
-        }
-        p.slab = g_slab;
+        // this stream's slab (96 MiB by default, grown on demand - never inside a capture: there the factor shrinks to what the slab
+        // reserved before the capture holds, down to whole-K tiles)
+        size_t need = (size_t)splitk * a.M * a.N * sizeof(float), have = 0;
+        void* slab = nullptr;
+        { int r = vz_stream_ws(0, s, std::max(need, SLAB_DEFAULT), false, &slab, &have); if (r) return r; }
+        while (splitk > 1 && (size_t)splitk * a.M * a.N * sizeof(float) > have) --splitk;
+        p.splitk = splitk;
+        p.slab = splitk > 1 ? (float*)slab : nullptr;
     }
     vz_launch_timed(gemm_bf16_kernel, dim3(tiles * splitk), dim3(256), GEMM_LDS, s, p);
     VZ_LAUNCH_CHECK();

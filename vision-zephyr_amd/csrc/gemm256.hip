@@ -657,8 +657,8 @@ int g_gemm256_drain = 0;     // vz_tune_set(11, v)
 int g_gemm256_skew = 2;      // vz_tune_set(5, v): K-tiles by which even / odd stream-K workgroups lead / lag
 
 int vz_init_gemm256_kernel() {
-    static bool done = false;
-    if (done) return VZ_OK;
+    static VzDeviceOnce once;
+    if (!vz_device_first(once)) return VZ_OK;
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES));
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES));
     int dev = 0;
@@ -666,7 +666,6 @@ int vz_init_gemm256_kernel() {
     VZ_CHECK_HIP(hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev));
     VZ_CHECK_HIP(hipMalloc((void**)&g_stamps, (size_t)4096 * 16 * sizeof(long long)));
     VZ_CHECK_HIP(hipDeviceSynchronize());
-    done = true;
     return VZ_OK;
 }
 

@@ -486,10 +486,9 @@ int vz_launch_gemm_fp8(const Fp8LinearArgs& a, hipStream_t s) {
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     // measured at M = 2048 (tools/bench_fp8.py): QKV (192 tiles) 70.5 vs 99.9 us, gate|up (896) 291 vs 314; O (128 tiles) 65.4 vs 58.5, down (128) 130 vs 128
     if (g_fp8_gemm_choice != 1 && (g_fp8_gemm_choice == 2 || t256 >= 160)) return vz_launch_gemm256_fp8(a, s);
-    static bool attr = false;
-    if (!attr) {
+    static VzDeviceOnce attr;
+    if (vz_device_first(attr)) {
         VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FP8_LDS));
-        attr = true;
     }
     Fp8Params p;
     p.A8 = a.A8; p.ascale = a.ascale; p.W8 = a.W8; p.wscale = a.wscale; p.C = a.C; p.bias = a.bias; p.residual = a.residual;

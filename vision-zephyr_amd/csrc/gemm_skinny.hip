@@ -542,10 +542,9 @@ size_t skinny_lds(const LinearArgs& a) {
 
 template <bool SWIGLU, bool NORM, int NW, bool FP8>
 int launch_nw(const SkinnyParams& p, int blocks, size_t lds, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static VzDeviceOnce attr;
+    if (vz_device_first(attr)) {
         VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_kernel<SWIGLU, NORM, NW, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     vz_launch_timed(skinny_kernel<SWIGLU, NORM, NW, FP8>, dim3(blocks), dim3(NW * 64), lds, s, p);
     VZ_LAUNCH_CHECK();
@@ -576,8 +575,8 @@ bool vz_skinny_ok(const LinearArgs& a) {
 }
 
 int vz_init_skinny_kernels() {
-    static bool done = false;
-    if (done) return VZ_OK;
+    static VzDeviceOnce once;
+    if (!vz_device_first(once)) return VZ_OK;
     // every variant a captured decode step can reach gets its dynamic-LDS limit now (never inside a stream capture)
 #define VZ_SK_ATTR(SW, NM, W)                                                                                                                   \
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_kernel<SW, NM, W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
@@ -596,7 +595,6 @@ int vz_init_skinny_kernels() {
         VZ_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
         g_num_cu_skinny = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    done = true;
     return VZ_OK;
 }
 
@@ -626,8 +624,8 @@ int vz_launch_skinny(const LinearArgs& a, hipStream_t s) {
     if (a.M > 16) {          // 17..64 rows: two / four B operands per weight fragment
         const bool four = blocks >= 512 && (p.K >> 6) >= 16;
 #define VZ_WIDE(SW, NWV, F8, MHV) do { \
-            static bool attr = false; \
-            if (!attr) { VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_wide_kernel<SW, NWV, F8, MHV>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr = true; } \
+            static VzDeviceOnce attr; \
+            if (vz_device_first(attr)) { VZ_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_wide_kernel<SW, NWV, F8, MHV>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); } \
             vz_launch_timed(skinny_wide_kernel<SW, NWV, F8, MHV>, dim3(blocks), dim3(NWV * 64), (size_t)NWV * 2 * MHV * 64 * 4 * sizeof(float), s, p); \
             VZ_LAUNCH_CHECK(); return VZ_OK; } while (0)
 #define VZ_WIDE_MH(SW, NWV, F8) do { if (a.M > 32) VZ_WIDE(SW, NWV, F8, 4); VZ_WIDE(SW, NWV, F8, 2); } while (0)

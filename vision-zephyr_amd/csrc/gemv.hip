@@ -279,10 +279,9 @@ int launch_variant(const GemvParams& p0, hipStream_t s, size_t lds) {
     int cap = NW == 4 ? 2048 : 512;
     if (g_gemv_variant >= 7 && g_gemv_variant <= 10) cap = (g_gemv_variant & 1) ? 256 : 512;      // experiments: one / two workgroups per CU
     if (blocks > cap) blocks = cap;
-    static bool attr = false;
-    if (!attr) {
+    static VzDeviceOnce attr;
+    if (vz_device_first(attr)) {
         VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<MB, R, U, NT, FP8, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NW == 4 ? 64 * 1024 : 160 * 1024));
-        attr = true;
     }
     vz_launch_timed(gemv_bf16_kernel<MB, R, U, NT, FP8, NW>, dim3(blocks), dim3(NW * 64), lds, s, p);
     VZ_LAUNCH_CHECK();
@@ -342,8 +341,8 @@ bool vz_gemv_ok(const LinearArgs& a) {
 int vz_init_gemv_kernels() {
     // every variant sets its own dynamic-LDS limit on first use; make the production ones resident now so the
     // first use never happens inside a stream capture
-    static bool done = false;
-    if (done) return VZ_OK;
+    static VzDeviceOnce once;
+    if (!vz_device_first(once)) return VZ_OK;
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<1, 2, 8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<1, 2, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<1, 2, 8, true, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -358,7 +357,6 @@ int vz_init_gemv_kernels() {
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<4, 2, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<8, 2, 8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_bf16_kernel<8, 2, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    done = true;
     return VZ_OK;
 }
 

@@ -203,11 +203,10 @@ __global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ 
 static bool g_sample_lds_ok = false;
 // dynamic-LDS limit of the staged kernel (128 KiB for a 32768-wide row), set once and never inside a stream capture
 int vz_init_sampling_kernels() {
-    static bool done = false;
-    if (done) return VZ_OK;
+    static VzDeviceOnce once;
+    if (!vz_device_first(once)) return VZ_OK;
     VZ_CHECK_HIP(hipFuncSetAttribute((const void*)sample_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * (int)sizeof(float)));
     g_sample_lds_ok = true;
-    done = true;
     return VZ_OK;
 }
 

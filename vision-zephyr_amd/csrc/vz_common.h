@@ -108,6 +108,15 @@ void vz_set_error(const char* fmt, ...);
         }                                                                                    \
     } while (0)
 
+// ---- once-per-DEVICE initialisation (hipFuncSetAttribute is a per-device setting: a process-wide `static bool done` would leave
+// the second device of a process with the default dynamic-LDS limit) ----
+struct VzDeviceOnce { unsigned long long seen[4] = {0, 0, 0, 0}; };
+bool vz_device_first(VzDeviceOnce& o);      // true exactly once per (o, current device); thread-safe (gemm.hip)
+// per-(kind, device, stream) scratch for split-K slabs / partial tiles / arrival tickets (gemm.hip).  kind 0: 128^2 GEMM slab,
+// 1: gemm_wide partial tiles, 2: gemm_wide tickets (zeroed), 3: decode-chain hand-off state (zeroed).  Inside a stream capture nothing is
+// allocated: *out / *out_bytes report what exists (reserve before capturing).
+int vz_stream_ws(int kind, hipStream_t s, size_t min_bytes, bool zero, void** out, size_t* out_bytes);
+
 // ---- internal launchers shared between the op-level C ABI and the engine ----
 struct LinearArgs {
     const bf16_t* A; int lda;
@@ -124,6 +133,8 @@ struct LinearArgs {
     // optional MFMA-fragment-tiled copy of W (vz_launch_tile_weights: [N/16][K/64][2][64 lanes][8]): the 2..64-row weight stream
     // (gemm_skinny.hip) then reads 1 KiB contiguous per wave-instruction instead of 16 rows x 64 bytes; same values, same k order
     const bf16_t* Wt = nullptr;
+    // optional fragment-tiled copy of W8 (vz_launch_tile_weights_fp8: [N/16][K/64][64 lanes][16]): the 17..64-row e4m3 stream of gemm_wide.hip
+    const unsigned char* W8t = nullptr;
     // 17..64 rows may take the MFMA weight stream (rows = independent sequences of a decode batch).  Off for the engine's prefill /
     // Q-Former linears: there a row's result must not depend on how many rows sit beside it (the tile GEMM's split-K is a
     // function of N and K only; tests/test_stages_gpu.py::test_qformer), and 32 / 64 / 96 rows must all take the same kernel.
@@ -152,6 +163,9 @@ int vz_launch_gemm256_fp8(const Fp8LinearArgs& a, hipStream_t s);      // gemm25
 bool vz_wide_ok(const LinearArgs& a);
 bool vz_wide_engine_ok(const LinearArgs& a);     // the shapes an engine's decode step routes there (no K split)
 int vz_launch_wide(const LinearArgs& a, hipStream_t s);
+int vz_launch_tile_weights_fp8(const unsigned char* W8, int N, int K, int ldw, unsigned char* W8t, hipStream_t s);
+int vz_wide_reserve(hipStream_t s);             // K-split scratch of a stream, allocated outside a capture
+extern int g_wide_fp8_splits;
 int vz_init_wide_kernels();
 extern int g_wide_mode;
 int vz_linear_check_common(const LinearArgs& a);

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libviszephyr_hip.so")
 
 VZ_OK, VZ_ERR_ARG, VZ_ERR_HIP, VZ_ERR_STATE, VZ_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 VZ_ASYNC_STREAMK = 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
 K_GEMM, K_GEMV, K_ATTN, K_ATTN_DEC, K_NORM, K_OTHER, K_FUSED, K_COMM = range(8)
 
@@ -46,6 +46,8 @@ SYMBOLS = {
     "vz_op_linear": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "vz_op_tile_weights": (_I, [_P, _I, _I, _I, _P, _P]),
     "vz_op_linear_tiled": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _F, _P]),
+    "vz_op_tile_weights_fp8": (_I, [_P, _I, _I, _I, _P, _P]),
+    "vz_op_linear_tiled_fp8": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "vz_engine_prefill_fp8": (_I, [_P, _I]),
     "vz_op_rmsnorm_quant_fp8": (_I, [_P, _I, _P, _F, _P, _I, _P, _I, _I, _P]),
     "vz_op_quant_rows_fp8": (_I, [_P, _I, _P, _I, _P, _I, _I, _P]),
@@ -93,7 +95,7 @@ SYMBOLS = {
     "vz_test_corrupt_streamk": (_I, [_P, _I, _I, _I]),
     "vz_engine_unset_weight": (_I, [_P, C.c_char_p]),
     "vz_llm_decode_sampling": (_I, [_P, _I, _F, _I, _F, C.c_ulonglong, _I]),
-    "vz_llm_decode_ring": (_I, [_P, _P, _I]),
+    "vz_llm_decode_ring": (_I, [_P, _P, _I, _I]),
     "vz_train_create": (_I, [_P, C.POINTER(_P), _P]),
     "vz_train_destroy": (_I, [_P]),
     "vz_train_set_master": (_I, [_P, C.c_char_p, _P, _L, _P]),
@@ -199,6 +201,27 @@ def tile_weights(w: torch.Tensor) -> torch.Tensor:
     wt = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
     check(lib().vz_op_tile_weights(ptr(w), w.shape[0], w.shape[1], w.stride(0), ptr(wt), stream_ptr(w.device)))
     return wt
+
+
+def tile_weights_fp8(w8: torch.Tensor) -> torch.Tensor:
+    """fragment-tiled copy of dense e4m3 rows (uint8 [N, K]) for the 17..64-row W8A16 stream of gemm_wide.hip."""
+    _need_cuda(w8)
+    assert w8.dtype == torch.uint8 and w8.dim() == 2 and w8.stride(1) == 1
+    wt = torch.empty(w8.numel(), dtype=torch.uint8, device=w8.device)
+    check(lib().vz_op_tile_weights_fp8(ptr(w8), w8.shape[0], w8.shape[1], w8.stride(0), ptr(wt), stream_ptr(w8.device)))
+    return wt
+
+
+def linear_tiled_fp8(x: torch.Tensor, w8t: torch.Tensor, wscale: torch.Tensor, N: int, bias=None, residual=None, act: int = ACT_NONE,
+                     out_fp32=False) -> torch.Tensor:
+    """epi(x @ (wscale[:, None] * e4m3(W8))^T) for 17 <= M <= 64 rows on the tiled e4m3 copy (gemm_wide.hip, W8A16)."""
+    _need_cuda(x, w8t, wscale, bias, residual)
+    M, K = x.shape
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    out = torch.empty(M, n_out, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=x.device)
+    check(lib().vz_op_linear_tiled_fp8(ptr(x), x.stride(0), ptr(w8t), ptr(wscale), ptr(out), out.stride(0), M, N, K, ptr(bias),
+                                       ptr(residual), 0 if residual is None else residual.stride(0), act, int(out_fp32), stream_ptr(x.device)))
+    return out
 
 
 def linear_tiled(x: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, bias=None, residual=None, act: int = ACT_NONE, out_fp32=False,

@@ -108,7 +108,8 @@ class Engine:
             B.check(self.lib.vz_engine_unset_weight(self.h, nt.encode()))
         if not (self.weight_fp8 and self._FP8_NAMES.match(name)):
             return
-        for n in self._fp8_names(name):
+        n8, ns = self._fp8_names(name)
+        for n in (n8, ns, n8 + "t"):          # e4m3 rows, their scales, the fragment-tiled e4m3 copy
             if n in self.w:
                 del self.w[n]
                 self._registered.discard(n)
@@ -363,12 +364,21 @@ class Engine:
             self._registered.discard(name)
 
     def _tile_decode_weights(self):
-        """bf16 engines: every decode-side Zephyr linear gets a copy in MFMA-fragment order (vz_op_tile_weights; +14.5 GB for
-        Zephyr-7B) that the 2..64-row decode steps stream with 1-KiB wave-instructions; same values, same k order as the
-        row-major tensor the prefill GEMMs and the 1-row GEMV keep using.  VZ_DECODE_TILED=0 turns it off."""
+        """every decode-side Zephyr linear gets a copy in MFMA-fragment order that the 2..64-row decode steps stream with 1-KiB
+        wave-instructions; same values, same k order as the row-major tensor the prefill GEMMs and the 1-row GEMV keep using.
+        bf16 engines: vz_op_tile_weights on the bf16 tensors (+14.5 GB for Zephyr-7B).  e4m3 engines (round 3): vz_op_tile_weights_fp8
+        on the e4m3 copies (+7.3 GB; their 17..64-row steps stream those, 2..16 rows keep the row-major e4m3 rows).
+        VZ_DECODE_TILED=0 turns it off."""
         if os.environ.get("VZ_DECODE_TILED", "1") == "0":
             return
         for name in [n for n in self.w if self._FP8_NAMES.match(n)]:
+            if self.weight_fp8:
+                n8 = self._fp8_names(name)[0]
+                w8 = self.w.get(n8)
+                if w8 is None or n8 + "t" in self.w or w8.shape[0] % 128 or w8.shape[1] % 1024:
+                    continue
+                self.w[n8 + "t"] = B.tile_weights_fp8(w8)
+                continue
             w = self.w[name]
             if name + "t" in self.w or w.shape[0] % 16 or w.shape[1] % 64:
                 continue
@@ -377,7 +387,7 @@ class Engine:
     def finalize(self):
         if self.weight_fp8:
             self._quantize_decode_weights()
-        if self.max_batch > (32 if self.weight_fp8 else 1):      # (an e4m3 engine streams e4m3 rows up to 32 rows; beyond, the bf16 routes)
+        if self.max_batch > (16 if self.weight_fp8 else 1):      # (an e4m3 engine streams row-major e4m3 rows up to 16 rows, the tiled e4m3 copies beyond)
             self._tile_decode_weights()
         for name, t in self.w.items():
             if name in self._registered:
@@ -510,11 +520,14 @@ class Engine:
                                                 int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_counter)))
 
     def set_ring(self, ring: Optional[torch.Tensor]):
-        """host-visible (pinned) int32 ring the step tails write their tokens to (slot = draw counter mod len); None = off."""
+        """host-visible (pinned) int32 ring the step tails write their tokens to: [slots] for a one-row batch or [rows, slots]
+        (slot = draw counter mod slots); None = off.  decode_steps refuses a batch with more rows than the ring has."""
+        rows = slots = 0
         if ring is not None:
-            assert ring.dtype == torch.int32 and ring.is_pinned() and ring.dim() == 1 and ring.numel() >= 2
+            assert ring.dtype == torch.int32 and ring.is_pinned() and ring.dim() in (1, 2) and ring.is_contiguous() and ring.shape[-1] >= 2
+            rows, slots = (1 if ring.dim() == 1 else int(ring.shape[0])), int(ring.shape[-1])
         self._ring_keep = ring
-        B.check(self.lib.vz_llm_decode_ring(self.h, B.ptr(ring), 0 if ring is None else ring.numel()))
+        B.check(self.lib.vz_llm_decode_ring(self.h, B.ptr(ring), slots, rows))
 
     def check_async(self):
         """raise if a bounded device-side wait expired since the last check (outputs invalid): the stream-K fix-up of
