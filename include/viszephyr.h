@@ -37,6 +37,7 @@ extern "C" {
 /* values of the async error word (vz_engine_async_error / vz_op_async_error): which bounded device-side wait expired */
 /* (1 was the hand-off of the one-launch batch-1 attention half, removed in round 2: it never beat the three kernels) */
 #define VZ_ASYNC_STREAMK 2    /* stream-K fix-up of the 256^2 GEMM: the tile was written as NaN, never as a sum of stale slots */
+#define VZ_ASYNC_PERSIST 3    /* a phase hand-off of the persistent decode-token kernel (decode_persist.hip) expired: that token's logits are garbage */
 
 typedef void* vz_stream;
 typedef struct vz_engine vz_engine;
@@ -292,6 +293,11 @@ int vz_op_sample(const float* d_logits, int rows, int cols, float temperature, i
 /* how the last vz_llm_decode_steps ran: *graph = 1 when a captured hipGraph was replayed; *comm_in_graph = 1 when the RCCL
  * collectives of a tensor-parallel engine are part of that graph (0 = eager steps, e.g. after RCCL refused the capture) */
 int vz_llm_decode_mode(vz_engine* e, int* graph, int* comm_in_graph);
+/* Batch-1 decode on an MI355X (ABI 10): with one row, one GPU, bf16 weights and the Zephyr-7B geometry vz_llm_decode_steps runs every
+ * token as ONE resident grid (decode_persist.hip: the 161 launches of a step become phases with in-launch hand-offs; bit-identical
+ * logits); vz_tune_set(28, 0) keeps the launch chain.  A phase hand-off that expires raises VZ_ASYNC_PERSIST (vz_engine_async_error).
+ * vz_test_persist_poke is a test hook: *mode = 1 if the last steps ran that way; word >= 0 presets an arrival counter. */
+int vz_test_persist_poke(vz_engine* e, int word, unsigned value, int* mode, vz_stream stream);
 /* batch-1 decode runs QKV GEMV + attention + O GEMV of a layer as ONE launch whose roles hand over through device-side counters;
  * every device-side wait is bounded and raises a word when it expires.  Reads and clears that word (blocking): *err != 0 = the
  * outputs since the previous call are invalid. */
@@ -345,7 +351,8 @@ int vz_op_anyres_tiles(const void* d_global, const void* d_resized, int nh, int 
  *       d_vis_rows int32 [T*32] (row of [B*S] each visual token was spliced into, -1 = cut off), d_labels int32 [B,S] (HF
  *       labels; the shift happens inside) and inv_n = 1 / (valid targets of the whole batch).
  *   vz_train_loss_sum           sum over the rows of the last micro-batch of (logsumexp - target logit)  (blocking)
- *   vz_train_allreduce          RCCL all-reduce (sum) of the flat gradient arena, 256 MiB buckets; no-op without vz_train_comm_init
+ *   vz_train_allreduce          RCCL all-reduce (ncclAvg: the mean over the data-parallel ranks of their mean-loss gradients, as
+ *                               DeepSpeed / HF Trainer reduce them) of the flat gradient arena, 256 MiB buckets; no-op without vz_train_comm_init
  *   vz_train_adamw_step         torch.optim.AdamW (no amsgrad) on every projector tensor; rewrites the engine's working copies,
  *                               clears the gradients
  * ------------------------------------------------------------------------------------------ */

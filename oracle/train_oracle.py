@@ -4,7 +4,9 @@ Stage 1 trains the Q-Former projector only (`ref:vis_zephyr/train/train.py:817-8
 `model.get_model().mm_projector.parameters()` re-enabled), on the token cross-entropy of the caption through the frozen Zephyr
 (`ref:vis_zephyr/model/language_model/vis_zephyr.py:51-98` hands `labels` to HF's `MistralForCausalLM.forward`, whose
 `ForCausalLMLoss` shifts by one, ignores -100 and takes the mean over the remaining positions), with HF Trainer's AdamW
-(`ref:script/pretrain.sh:39-42`: lr 2e-5, weight decay 0, cosine schedule with 3 % warm-up; betas 0.9 / 0.999, eps 1e-8).
+(`ref:script/pretrain.sh:16,38-41`: the projector groups run at --mm_projector_lr 2e-3 - `ref:vis_zephyr/train/vis_zephyr_trainer.py:224-302`;
+the 2e-5 of --learning_rate only reaches groups that are empty in Stage 1 - weight decay 0, cosine schedule with 3 % warm-up; betas
+0.9 / 0.999, eps 1e-8).
 
 The forward is the pinned restatement in vz_oracle.py; the gradients are torch autograd THROUGH that restatement (the CLIP tower
 runs under no_grad exactly as `ref:vis_zephyr/model/vision_encoder/vision_encoder.py:80` decorates it), so this file adds no
@@ -57,7 +59,7 @@ def stage1_grads(cfg, sd, input_ids, attention_mask, labels, images, P: O.Prec =
     return loss.detach(), {k: v.grad for k, v in leaves.items()}
 
 
-def lr_at(step: int, total_steps: int, base_lr: float = 2e-5, warmup_ratio: float = 0.03) -> float:
+def lr_at(step: int, total_steps: int, base_lr: float = 2e-3, warmup_ratio: float = 0.03) -> float:
     """HF `get_cosine_schedule_with_warmup` as the Trainer builds it: linear warm-up over ceil(ratio * total) steps, then half a cosine
     to zero.  `step` counts optimiser steps already taken (0 for the first update)."""
     warm = math.ceil(total_steps * warmup_ratio)

@@ -101,7 +101,10 @@ def test_configs3_full_size_rows_vs_alone_and_loss(deep64, band32):
         assert tuple(alone.logits.shape) == (1, S, cfg.vocab)
         e = _rel(alone.logits[0].cpu().numpy(), logits[b].cpu().numpy())
         worst = max(worst, e)
-        assert e <= band_tol(band32), f"sample {b}: alone vs inside the batch of {Bn}: rel-L2 {e:.3e}, bf16 band {band32:.3e}"
+        # both sides are bf16 evaluations (the lone sample's 5 tiles take the 128^2 GEMM with K slices, the 80-tile chunks the 256^2
+        # pipeline; other row counts everywhere) that each sit inside the band around the exact result: independent errors of that
+        # size are sqrt(2) x the band apart (measured 5.9e-2 = 1.35 x; a decode step and its prefill row share the prefill and sit closer)
+        assert e <= band_tol(2.0 ** 0.5 * band32), f"sample {b}: alone vs inside the batch of {Bn}: rel-L2 {e:.3e}, bf16 band {band32:.3e}"
         assert int(alone.logits[0, -1].argmax()) == int(logits[b, -1].argmax()) or e > 0
     record("configs[3] full size rows vs alone", worst_rel_l2=worst, band=band32)
     model.engine.check_async()

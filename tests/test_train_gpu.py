@@ -144,3 +144,68 @@ def test_micro_batches_accumulate_and_one_rank_allreduce(env):
     torch.cuda.synchronize()
     for k, v in tr.reference_grads().items():
         assert torch.equal(v, before[k])
+
+
+def test_data_parallel_mean_of_rank_gradients(env):
+    """What the data-parallel all-reduce must produce (the reference: DeepSpeed ZeRO-2 under HF's Trainer AVERAGES the ranks' mean-loss
+    gradients; round 2 summed them): two ranks played in turn on this GPU - each back-propagates the mean loss of ITS sample - and the
+    mean of the two gradient arenas (ncclAvg's arithmetic, done here with torch on the arena views) against the single-rank gradient
+    of the two-sample batch.  Both samples carry the same number of text ids, so the Q-Former's text padding (Appendix A Q3) and the
+    target counts agree and mean-of-means = the global batch's gradient up to bf16 re-association; the SUM would be 2 x that."""
+    tr, cfg, synth = env["tr"], env["cfg"], __import__("vz_hip.synth", fromlist=["synth"])
+    from vz_hip import binding as B
+    ids = torch.stack([synth.synth_ids(20, cfg.vocab, image_pos=1, seed=41), synth.synth_ids(20, cfg.vocab, image_pos=1, seed=42)])
+    mask = torch.ones_like(ids)
+    lab = ids.clone()
+    lab[ids == -200] = -100
+    images = [synth.synth_tiles(2, seed=43), synth.synth_tiles(1, seed=44)]
+    B.check(B.lib().vz_tune_set(26, 0))           # whole-K tiles on both sides (see the micro-batch test)
+    try:
+        per_rank = []
+        for b in range(2):
+            tr.zero_grad()
+            tr.forward_backward(ids[b:b + 1], mask[b:b + 1], lab[b:b + 1], [images[b]])      # normalised by the rank's OWN target count
+            per_rank.append({k: v.clone() for k, v in tr.reference_grads().items()})
+        tr.zero_grad()
+        tr.forward_backward(ids, mask, lab, images)
+        both = {k: v.clone() for k, v in tr.reference_grads().items()}
+        tr.zero_grad()
+    finally:
+        B.check(B.lib().vz_tune_set(26, 1))
+    worst_avg, worst_sum = 0.0, 0.0
+    for k in both:
+        worst_avg = max(worst_avg, errs(0.5 * (per_rank[0][k] + per_rank[1][k]), both[k])[1])
+        worst_sum = max(worst_sum, errs(per_rank[0][k] + per_rank[1][k], both[k])[1])
+    record("stage1 data-parallel semantics", mean_of_rank_gradients_vs_global_batch=worst_avg, sum_vs_global_batch=worst_sum)
+    assert worst_avg <= 2e-2, worst_avg
+    assert worst_sum >= 0.9               # what round 2's ncclSum handed AdamW: twice the gradient
+
+
+def test_save_projector_writes_the_reference_checkpoint(env, tmp_path):
+    """`Stage1Trainer.save_projector` = the reference's Stage-1 checkpoint (ref:vis_zephyr/train/vis_zephyr_trainer.py:304-348:
+    `mm_projector.bin`, keys `model.mm_projector.*`, SURVEY Appendix C shapes); loading it back through the engine's own loader
+    (vz_hip/weights.py, the path ref:vis_zephyr/model/builder.py:118-120 takes) reproduces the working copies bit for bit."""
+    tr = env["tr"]
+    path = tr.save_projector(str(tmp_path))
+    sd = torch.load(path, map_location="cpu")
+    cfg = tr.eng.cfg
+    H, KD = cfg.hidden, cfg.qf_kv_dim
+    assert len(sd) == 165 and all(k.startswith("model.mm_projector.") for k in sd)
+    assert tuple(sd["model.mm_projector.learned_queries"].shape) == (32, H)
+    assert tuple(sd["model.mm_projector.blocks.3.cross_attn.k_proj_weight"].shape) == (H, KD)
+    assert tuple(sd["model.mm_projector.blocks.3.cross_attn.v_proj_weight"].shape) == (H, KD)
+    assert tuple(sd["model.mm_projector.blocks.3.cross_attn.in_proj_bias"].shape) == (3 * H,)
+    assert tuple(sd["model.mm_projector.blocks.0.self_attn.in_proj_weight"].shape) == (3 * H, H)
+    assert all(v.dtype == torch.bfloat16 for v in sd.values())
+    # k | v halves and the q | k | v bias against the engine's stacked tensors (bf16 of the fp32 masters = the engine's working copies)
+    kv = tr.master("qf.3.ca_kv.w")
+    assert torch.equal(sd["model.mm_projector.blocks.3.cross_attn.k_proj_weight"], kv[:H].to(torch.bfloat16).cpu())
+    assert torch.equal(sd["model.mm_projector.blocks.3.cross_attn.v_proj_weight"], kv[H:].to(torch.bfloat16).cpu())
+    qb, kvb = tr.master("qf.3.ca_q.b"), tr.master("qf.3.ca_kv.b")
+    assert torch.equal(sd["model.mm_projector.blocks.3.cross_attn.in_proj_bias"], torch.cat([qb, kvb]).to(torch.bfloat16).cpu())
+    # round trip through the loader's key map
+    before = {n: tr.eng.w[n].clone() for n in ("qf.queries", "qf.3.ca_kv.w", "qf.5.ffn2.w", "qf.7.sa_in.w")}
+    tr.eng.load_weights((k, v) for k, v in sd.items())
+    tr.eng.finalize()
+    for n, t in before.items():
+        assert torch.equal(tr.eng.w[n], t), n

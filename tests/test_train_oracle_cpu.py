@@ -50,10 +50,12 @@ def test_schedule_matches_hf():
     from transformers import get_cosine_schedule_with_warmup
     total = 1000
     par = torch.nn.Parameter(torch.zeros(1))
-    opt = torch.optim.AdamW([par], lr=2e-5)
+    opt = torch.optim.AdamW([par], lr=2e-3)            # --mm_projector_lr (ref:script/pretrain.sh:16): the projector groups' base rate
     sch = get_cosine_schedule_with_warmup(opt, num_warmup_steps=math.ceil(total * 0.03), num_training_steps=total)
     for step in range(total):
         assert abs(sch.get_last_lr()[0] - T.lr_at(step, total)) <= 1e-12, step
+        from vz_hip import train as HT
+        assert HT.lr_at(step, total) == T.lr_at(step, total)          # the product-side schedule is the same function
         opt.step()
         sch.step()
 

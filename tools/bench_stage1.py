@@ -77,7 +77,7 @@ if TRAIN:
     for it in range(4):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        losses.append(tr.step(ids, mask, labels, tiles, lr=2e-5, micro_batch=MB))
+        losses.append(tr.step(ids, mask, labels, tiles, lr=2e-3, micro_batch=MB)      # --mm_projector_lr (ref:script/pretrain.sh:16))
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     best = min(times[1:])

@@ -253,8 +253,11 @@ struct vz_engine {
     unsigned* d_ticket = nullptr; // arrival counters of the fused decode attention
     int* d_ferr = nullptr;        // raised by a bounded device-side wait that expired
     int nsplit = 32;                 // upper bound: a split takes >= 128 keys, the splits beyond ceil(len / 128) leave at once
+    VzTokState* tok = nullptr;          // persistent decode-token kernel (decode_persist.hip): per-layer pointer table + hand-off vectors + arrival counters
+    bool use_tok = false;               // the steps being launched run on it (decided per vz_llm_decode_steps call)
+    int tok_poke_word = -1; unsigned tok_poke_value = 0;      // TEST HOOK (vz_test_persist_poke): applied once, behind the next counter reset
     hipStream_t cap_stream = nullptr;   // stream capture is not allowed on the legacy null stream torch hands us
-    hipGraphExec_t dec_graph = nullptr; int dec_graph_B = 0, dec_graph_n = 0, dec_graph_nsplit = 0; long dec_graph_samp[6] = {0, 0, 0, 0, 0, 0}; int* dec_graph_out = nullptr; char* dec_graph_arena = nullptr;
+    hipGraphExec_t dec_graph = nullptr; int dec_graph_B = 0, dec_graph_n = 0, dec_graph_nsplit = 0, dec_graph_tok = -1; long dec_graph_samp[6] = {0, 0, 0, 0, 0, 0}; int* dec_graph_out = nullptr; char* dec_graph_arena = nullptr;
     int* h_pinned = nullptr;     // pinned staging for small host->device uploads
     size_t h_pinned_ints = 0;
     // profiling
@@ -498,6 +501,7 @@ extern "C" int vz_engine_destroy(vz_engine* e) {
     if (e->d_ferr) hipFree(e->d_ferr);
     if (e->d_xnorm) hipFree(e->d_xnorm);
     if (e->d_gather) (void)hipFree(e->d_gather);
+    vz_decode_persist_destroy(e->tok);
     if (e->comm) (void)ncclCommDestroy(e->comm);
     if (e->h_pinned) hipHostFree(e->h_pinned);
     delete e;
@@ -507,6 +511,11 @@ extern "C" int vz_engine_destroy(vz_engine* e) {
 // The captured decode graph freezes every pointer its kernels take (weights, rotary tables, the gathered-logits buffer, the
 // workspace): whoever replaces one of them drops the graph, the next vz_llm_decode_steps captures again.
 static int drop_decode_graph(vz_engine* e) {
+    if (e->tok) {                               // the persistent kernel's layer table freezes weight / cache pointers too
+        VZ_CHECK_HIP(hipDeviceSynchronize());
+        vz_decode_persist_destroy(e->tok);
+        e->tok = nullptr;
+    }
     if (!e->dec_graph) return VZ_OK;
     VZ_CHECK_HIP(hipDeviceSynchronize());       // a replay may still be running
     (void)hipGraphExecDestroy(e->dec_graph);
@@ -538,6 +547,7 @@ extern "C" int vz_engine_resize_vocab(vz_engine* e, int new_vocab) {
     if (new_vocab == e->c.vocab) return VZ_OK;
     VZ_CHECK_HIP(hipDeviceSynchronize());
     if (e->dec_graph) { (void)hipGraphExecDestroy(e->dec_graph); e->dec_graph = nullptr; }     // it holds the old logits width
+    if (e->tok) { vz_decode_persist_destroy(e->tok); e->tok = nullptr; }
     if (e->d_logits) { VZ_CHECK_HIP(hipFree(e->d_logits)); e->d_logits = nullptr; }
     e->c.vocab = new_vocab;
     e->Vp = new_vocab;
@@ -821,6 +831,7 @@ extern "C" int vz_embed_splice(vz_engine* e, const int* d_kind, const int* d_idx
 // call sites through RCCL (all-reduce over one rank = identity, all-gather = copy), so the collective plumbing - library,
 // dtypes, in-place buffers, stream order, the vocab-parallel gather + repack - runs on a single GPU.
 static int g_force_comm = 0;
+static int g_persist_decode = 1;   // vz_tune_set(28, v): 1 = batch-1 decode steps as one resident grid per token (decode_persist.hip), 0 = the launch chain
 static int g_attn_nsplit = 0;   // vz_tune_set(10, n): context splits of the fused decode attention (0 = engine default)
 static inline bool tp_local(const vz_engine* e) { return e->tp == 1 && !(g_force_comm && e->comm); }
 
@@ -1125,31 +1136,45 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
     bf16_t* act = m.take<bf16_t>((size_t)B * I);
     if (!m.ok) { vz_set_error("decode: workspace too small"); return VZ_ERR_STATE; }
     int rc = VZ_OK;
-    { ProfScope ps(e, K_OTHER, s); RC(vz_launch_embed_tokens(cur, B, H, WB("llm.embed", (long)c.vocab * H), x, s)); }
-    for (int i = 0; i < c.n_layers; ++i) {
-        const std::string p = "llm." + std::to_string(i) + ".";
-        RC(linear(e, 1, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps,
-                  W8(p + "qkv.w8", (long)QKV * H), WS(p + "qkv.ws", QKV)));
-        {
-            ProfScope ps(e, K_ATTN_DEC, s);
-            AttnDecodeFusedArgs a;
-            a.qkv = qkv; a.kc = kc_of(e, i); a.vc = vc_of(e, i); a.o = att; a.part = e->d_part; a.ticket = e->d_ticket;
-            a.cosT = e->cosT; a.sinT = e->sinT; a.pos = pos; a.slot = slot;
-            a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_ctx = c.max_ctx; a.nsplit = e->dec_nsplit; a.window = c.sliding_window;
-            a.scale = 0.08838834764831845f;
-            RC(vz_launch_attn_decode_fused(a, s));
-        }
-        RC(linear(e, 1, att, A, WB(p + "o.w", (long)H * A), A, x, H, B, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
-                  W8(p + "o.w8", (long)H * A), WS(p + "o.ws", H)));
-        RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
-        RC(linear(e, 1, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps,
-                  W8(p + "gu.w8", 2L * I * H), WS(p + "gu.ws", 2L * I)));
-        RC(linear(e, 1, act, I, WB(p + "down.w", (long)I * H), I, x, H, B, H, I, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
-                  W8(p + "down.w8", (long)I * H), WS(p + "down.ws", H)));
-        RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
+    if (e->use_tok && e->tok) {
+        // batch 1 on an MI355X: embedding row -> 32 layers -> logits as the phases of ONE resident grid (decode_persist.hip); same
+        // arithmetic as the launches below, bit for bit
+        VzTokArgs a;
+        a.embed = WB("llm.embed", (long)c.vocab * H); a.lm_head = WB("llm.lm_head", (long)e->Vp * H); a.final_norm = WF("llm.norm", H);
         if (rc) return rc;
+        a.cur = cur; a.pos = pos; a.slot = slot; a.step = step;
+        a.logits = e->d_logits; a.part = e->d_part; a.ticket = e->d_ticket; a.cosT = e->cosT; a.sinT = e->sinT; a.err = e->d_ferr;
+        a.vocab = c.vocab; a.max_ctx = c.max_ctx; a.nsplit = e->dec_nsplit; a.window = c.sliding_window; a.scale = 0.08838834764831845f; a.eps = c.rms_eps;
+        e->last_stream = s;
+        ProfScope ps(e, K_GEMV, s);
+        RC(vz_launch_decode_token(e->tok, a, s));
+    } else {
+        { ProfScope ps(e, K_OTHER, s); RC(vz_launch_embed_tokens(cur, B, H, WB("llm.embed", (long)c.vocab * H), x, s)); }
+        for (int i = 0; i < c.n_layers; ++i) {
+            const std::string p = "llm." + std::to_string(i) + ".";
+            RC(linear(e, 1, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps,
+                      W8(p + "qkv.w8", (long)QKV * H), WS(p + "qkv.ws", QKV)));
+            {
+                ProfScope ps(e, K_ATTN_DEC, s);
+                AttnDecodeFusedArgs a;
+                a.qkv = qkv; a.kc = kc_of(e, i); a.vc = vc_of(e, i); a.o = att; a.part = e->d_part; a.ticket = e->d_ticket;
+                a.cosT = e->cosT; a.sinT = e->sinT; a.pos = pos; a.slot = slot;
+                a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_ctx = c.max_ctx; a.nsplit = e->dec_nsplit; a.window = c.sliding_window;
+                a.scale = 0.08838834764831845f;
+                RC(vz_launch_attn_decode_fused(a, s));
+            }
+            RC(linear(e, 1, att, A, WB(p + "o.w", (long)H * A), A, x, H, B, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
+                      W8(p + "o.w8", (long)H * A), WS(p + "o.ws", H)));
+            RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
+            RC(linear(e, 1, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps,
+                      W8(p + "gu.w8", 2L * I * H), WS(p + "gu.ws", 2L * I)));
+            RC(linear(e, 1, act, I, WB(p + "down.w", (long)I * H), I, x, H, B, H, I, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
+                      W8(p + "down.w8", (long)I * H), WS(p + "down.ws", H)));
+            RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
+            if (rc) return rc;
+        }
+        RC(lm_head_logits(e, x, B, e->d_logits, s, WF("llm.norm", H)));
     }
-    RC(lm_head_logits(e, x, B, e->d_logits, s, WF("llm.norm", H)));
     if (rc) return rc;
     if (d_logits_dbg) {
         // debug copy is indexed by the host (eager mode only)
@@ -1225,6 +1250,28 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     if (!tp_local(e)) RC(ensure_gather(e, B, s));
     int* step = e->d_state + 4 * c.max_batch;
     VZ_CHECK_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
+    // Batch 1, one GPU, bf16 weights, Zephyr-7B geometry on a 256-CU device: the steps run as ONE resident grid per token
+    // (decode_persist.hip; vz_tune_set(28, 0) = the launch chain).  Its pointer table is (re)built here, never inside a capture.
+    e->use_tok = false;
+    if (g_persist_decode && B == 1 && e->tp == 1 && tp_local(e) && !c.weight_fp8 && c.hidden == 4096 && c.inter == 14336 && c.n_heads == 32 &&
+        c.n_kv_heads == 8 && c.head_dim == 128 && c.vocab >= 256 && vz_decode_persist_supported()) {
+        if (!e->tok) {
+            std::vector<VzTokLayerHost> lt(c.n_layers);
+            int rc = VZ_OK;
+            const long H = c.hidden, QKV = (long)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim, I = c.inter;
+            for (int i = 0; i < c.n_layers; ++i) {
+                const std::string p = "llm." + std::to_string(i) + ".";
+                lt[i].qkv_w = WB(p + "qkv.w", QKV * H); lt[i].o_w = WB(p + "o.w", H * H); lt[i].gu_w = WB(p + "gu.w", 2 * I * H); lt[i].down_w = WB(p + "down.w", I * H);
+                lt[i].in_norm = WF(p + "in_norm", H); lt[i].post_norm = WF(p + "post_norm", H);
+                lt[i].kc = kc_of(e, i); lt[i].vc = vc_of(e, i);
+            }
+            if (rc) return rc;
+            RC(vz_decode_persist_create(lt.data(), c.n_layers, &e->tok));
+        }
+        RC(vz_decode_persist_reset(e->tok, s));         // arrival counters restart with the step counter
+        if (e->tok_poke_word >= 0) { RC(vz_decode_persist_poke(e->tok, e->tok_poke_word, e->tok_poke_value, s)); e->tok_poke_word = -1; }
+        e->use_tok = true;
+    }
     // Capacity (the cache append writes slot = len - 1 of the row, the rotary tables are read at pos): every live row must still fit
     // after n steps.  Parked rows (continuous batching) are not checked: the step tail saturates their slot / position on the device.
     int len_max = 0;
@@ -1262,7 +1309,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     long samp_key[6] = {e->samp_on, e->samp_top_k, 0, 0, (long)(uintptr_t)e->ring, e->ring_n};
     memcpy(&samp_key[2], &e->samp_temp, 4); memcpy(&samp_key[3], &e->samp_top_p, 4);
     if (!e->dec_graph || e->dec_graph_B != B || e->dec_graph_n != n || e->dec_graph_out != d_out_ids || e->dec_graph_arena != e->arena ||
-        e->dec_graph_nsplit != e->dec_nsplit || memcmp(e->dec_graph_samp, samp_key, sizeof(samp_key)) != 0) {
+        e->dec_graph_nsplit != e->dec_nsplit || e->dec_graph_tok != (int)e->use_tok || memcmp(e->dec_graph_samp, samp_key, sizeof(samp_key)) != 0) {
         if (e->dec_graph) { hipGraphExecDestroy(e->dec_graph); e->dec_graph = nullptr; }
         hipGraph_t graph;
         if (!e->cap_stream) VZ_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
@@ -1285,7 +1332,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
             for (int i = 0; i < n; ++i) RC(decode_step_launch(e, d_out_ids, n, nullptr, s));
             return VZ_OK;
         }
-        e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena; e->dec_graph_nsplit = e->dec_nsplit; memcpy(e->dec_graph_samp, samp_key, sizeof(samp_key));
+        e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena; e->dec_graph_nsplit = e->dec_nsplit; e->dec_graph_tok = (int)e->use_tok; memcpy(e->dec_graph_samp, samp_key, sizeof(samp_key));
     }
     for (int i = 0; i < n; ++i) VZ_CHECK_HIP(hipGraphLaunch(e->dec_graph, s));
     return VZ_OK;
@@ -1332,6 +1379,17 @@ extern "C" int vz_op_async_error(vz_stream stream, int* err) {
 
 // TEST HOOK: overwrite the {arrive, ready} pair of stream-K remainder tile `tile` on `stream` (tests/test_ops_gpu.py drives an
 // expired fix-up wait with it: the launch must end, raise VZ_ASYNC_STREAMK and write NaN, never a sum of stale slots)
+// TEST HOOK: preset arrival-counter shard `word` (0..7; 8 = the abort word) of the persistent decode-token kernel's hand-off state for
+// the NEXT vz_llm_decode_steps call - tests/test_persist_gpu.py makes a shard lag so that a wait can never be met: the launch must END,
+// raise VZ_ASYNC_PERSIST, and the call after it (which zeroes the counters again) must be clean.  *mode (may be null) receives 1 if the last steps ran on the
+// persistent kernel.
+extern "C" int vz_test_persist_poke(vz_engine* e, int word, unsigned value, int* mode, vz_stream stream) {
+    VZ_CHECK_ARG(e && word <= 8, "persist_poke: bad argument");
+    (void)stream;
+    if (mode) *mode = e->use_tok && e->tok ? 1 : 0;
+    if (word >= 0) { e->tok_poke_word = word; e->tok_poke_value = value; }      // applied by the next vz_llm_decode_steps, behind its counter reset
+    return VZ_OK;
+}
 extern "C" int vz_test_corrupt_streamk(vz_stream stream, int tile, int arrive, int ready) {
     return vz_gemm256_corrupt_tickets((hipStream_t)stream, tile, arrive, ready);
 }
@@ -1357,6 +1415,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 24) { vz_set_splitk_cap(value); return VZ_OK; }
     if (knob == 25) { g_qf_kv_all = value; return VZ_OK; }
     if (knob == 27) { g_wide_fp8_splits = value; return VZ_OK; }
+    if (knob == 28) { g_persist_decode = value; return VZ_OK; }
     if (knob == 26) { vz_set_splitk_mid(value); return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }

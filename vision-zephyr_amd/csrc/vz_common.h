@@ -245,6 +245,22 @@ struct AttnDecodeArgs {
 };
 int vz_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 
+// decode_persist.hip: one resident grid per decoded token (batch 1, Zephyr-7B geometry, bf16 weights)
+struct VzTokLayerHost { const void *qkv_w, *o_w, *gu_w, *down_w; const float *in_norm, *post_norm; void *kc, *vc; };
+struct VzTokArgs {
+    const void *embed, *lm_head; const float* final_norm;
+    const int *cur, *pos, *slot, *step;
+    float* logits; float* part; unsigned* ticket; const float *cosT, *sinT; int* err;
+    int vocab, max_ctx, nsplit, window; float scale, eps;
+};
+struct VzTokState;
+bool vz_decode_persist_supported();
+int vz_decode_persist_create(const VzTokLayerHost* layers, int n_layers, VzTokState** out);
+void vz_decode_persist_destroy(VzTokState* st);
+int vz_decode_persist_reset(VzTokState* st, hipStream_t s);
+int vz_decode_persist_poke(VzTokState* st, int word, unsigned value, hipStream_t s);
+int vz_launch_decode_token(VzTokState* st, const VzTokArgs& a, hipStream_t s);
+
 // decode attention with RoPE + KV append + split combine fused into one launch (attn_decode.hip)
 struct AttnDecodeFusedArgs {
     const bf16_t* qkv;     // [B, (Hq+2Hkv)*D]

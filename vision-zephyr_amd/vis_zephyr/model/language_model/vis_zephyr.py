@@ -424,7 +424,12 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         optional `images` ([N,3,336,336]) / `images_size`, optional `max_new_tokens` - with CONTINUOUS batching: up to `rows`
         KV-cache rows decode together; a row whose sequence ends (eos or its token budget) is re-armed with the next request at
         the next host sync (every `sync_every` steps), the other rows keep decoding.  Yields `(index, LongTensor[n_new])` in
-        completion order; every sequence gets the tokens `generate` gives it alone (rows are independent).
+        completion order.  Rows are independent sequences: every sequence gets the tokens `generate` gives it alone UP TO kernel-route
+        re-association - the number of rows decoding together (GEMV / MFMA weight stream / tile GEMM by row count) and, for a shared
+        admission prefill, the padded group size (split-K factor of the tile GEMM, fp8 MFMA threshold of a prefill_fp8 engine) choose
+        different but equally accurate bf16 evaluation orders, so a near-tie between two candidates can flip.  With the route choice
+        pinned (vz_tune_set(26, 0)) the ids are bit-identical (tests/test_stages_gpu.py::test_continuous_batching_matches_static_batches);
+        at the default knobs they agree up to the first near-tie (::test_continuous_batching_default_knobs_near_tie).
 
         Admissions are BATCHED when the engine has cache rows to spare (`max_batch > rows`): all requests entering at one sync
         share one Zephyr prefill (right-padded, up to `admit` = min(max_batch - rows, 16) sequences) into the spare rows, one

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libviszephyr_hip.so")
 
 VZ_OK, VZ_ERR_ARG, VZ_ERR_HIP, VZ_ERR_STATE, VZ_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 VZ_ASYNC_STREAMK = 2
+VZ_ASYNC_PERSIST = 3
 ABI_VERSION = 10
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
 K_GEMM, K_GEMV, K_ATTN, K_ATTN_DEC, K_NORM, K_OTHER, K_FUSED, K_COMM = range(8)
@@ -79,6 +80,7 @@ SYMBOLS = {
     "vz_llm_decode_begin": (_I, [_P, _I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
     "vz_llm_decode_mode": (_I, [_P, _P, _P]),
+    "vz_test_persist_poke": (_I, [_P, _I, C.c_uint, _P, _P]),
     "vz_engine_async_error": (_I, [_P, _P]),
     "vz_tune_set": (_I, [_I, _I]),
     "vz_engine_resize_vocab": (_I, [_P, _I]),

@@ -535,8 +535,19 @@ class Engine:
         err = C.c_int(0)
         B.check(self.lib.vz_engine_async_error(self.h, C.byref(err)))
         if err.value:
-            what = {B.VZ_ASYNC_STREAMK: "stream-K fix-up of the 256^2 GEMM (another launch shared its tickets?)"}.get(err.value, f"code {err.value}")
+            what = {B.VZ_ASYNC_STREAMK: "stream-K fix-up of the 256^2 GEMM (another launch shared its tickets?)",
+                    B.VZ_ASYNC_PERSIST: "phase hand-off of the persistent decode-token kernel"}.get(err.value, f"code {err.value}")
             raise RuntimeError(f"vz_hip: a bounded device-side wait expired ({what}); outputs since the last check are invalid")
+
+    def persist_mode(self) -> bool:
+        """True if the last decode_steps ran every token as one resident grid (decode_persist.hip)."""
+        m = C.c_int(0)
+        B.check(self.lib.vz_test_persist_poke(self.h, -1, 0, C.byref(m), self._s()))
+        return bool(m.value)
+
+    def persist_poke(self, word: int, value: int):
+        """TEST HOOK: preset arrival counter `word` (0..7; 8 = abort) of the persistent decode-token kernel for the next decode_steps."""
+        B.check(self.lib.vz_test_persist_poke(self.h, int(word), int(value) & 0xFFFFFFFF, None, self._s()))
 
     def decode_mode(self):
         """(graph replayed?, RCCL collectives inside the graph?) of the last decode_steps call."""

@@ -2,8 +2,10 @@
 
 What the reference runs per optimiser step (`ref:vis_zephyr/train/train.py:817-829` freezes everything but
 `model.get_model().mm_projector`; `ref:vis_zephyr/model/language_model/vis_zephyr.py:51-98` -> HF `ForCausalLMLoss`;
-`ref:vis_zephyr/train/vis_zephyr_trainer.py:224-302` builds AdamW for the projector parameters; `ref:script/pretrain.sh:39-42`
-lr 2e-5, weight decay 0, cosine schedule with 3 % warm-up; DeepSpeed ZeRO-2 = data parallelism with reduced gradients):
+`ref:vis_zephyr/train/vis_zephyr_trainer.py:224-302` builds AdamW with every `mm_projector` parameter in the groups whose lr is
+`--mm_projector_lr` = 2e-3 (`ref:script/pretrain.sh:16`; the 2e-5 of `--learning_rate`, `:38`, only reaches non-projector groups,
+which are empty in Stage 1), weight decay 0, HF's cosine schedule with 3 % warm-up scaling that 2e-3 (`:39-41`); DeepSpeed ZeRO-2 =
+data parallelism with AVERAGED gradients; `_save_checkpoint` (`ref:...vis_zephyr_trainer.py:304-348`) writes `mm_projector.bin`):
 
     loss = model(input_ids, attention_mask, labels=labels, images=images).loss ; loss.backward() ; optimizer.step()
 
@@ -26,9 +28,12 @@ from . import binding as B
 IGNORE_INDEX, IMAGE_TOKEN_INDEX = -100, -200
 
 
-def lr_at(step: int, total_steps: int, base_lr: float = 2e-5, warmup_ratio: float = 0.03) -> float:
-    """HF `get_cosine_schedule_with_warmup` as the Trainer builds it (ref:script/pretrain.sh:40-42): linear warm-up over
-    ceil(ratio * total) steps, then half a cosine to zero; `step` = optimiser steps already taken."""
+MM_PROJECTOR_LR = 2e-3       # ref:script/pretrain.sh:16 (--mm_projector_lr): the base rate of the only trainable group of Stage 1
+
+
+def lr_at(step: int, total_steps: int, base_lr: float = MM_PROJECTOR_LR, warmup_ratio: float = 0.03) -> float:
+    """HF `get_cosine_schedule_with_warmup` as the Trainer builds it (ref:script/pretrain.sh:39-41) around the projector groups'
+    base rate: linear warm-up over ceil(ratio * total) steps, then half a cosine to zero; `step` = optimiser steps already taken."""
     warm = math.ceil(total_steps * warmup_ratio)
     if step < warm:
         return base_lr * step / max(1, warm)
@@ -257,12 +262,41 @@ class Stage1Trainer:
         B.check(self.lib.vz_train_adamw_step(self.h, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.eng._s()))
         self.steps_done += 1
 
-    def step(self, input_ids, attention_mask, labels, images, lr: Optional[float] = None, total_steps: int = 1000, micro_batch: Optional[int] = None) -> float:
-        """one optimiser step as HF's Trainer takes it: forward + backward, (all-reduce), AdamW with the scheduled learning rate."""
+    def step(self, input_ids, attention_mask, labels, images, lr: Optional[float] = None, total_steps: Optional[int] = None,
+             micro_batch: Optional[int] = None) -> float:
+        """one optimiser step as HF's Trainer takes it: forward + backward, (all-reduce: mean over the data-parallel ranks), AdamW with
+        the scheduled learning rate.  Either `lr` (explicit) or `total_steps` (the schedule's length: the Trainer knows it from the
+        dataset and the epoch count; there is no sensible default) must be given."""
+        if lr is None and total_steps is None:
+            raise ValueError("Stage1Trainer.step: pass lr=..., or total_steps=... for the cosine schedule around mm_projector_lr = 2e-3")
         loss = self.forward_backward(input_ids, attention_mask, labels, images, micro_batch)
         self.all_reduce()
-        self.optimizer_step(lr_at(self.steps_done, total_steps) if lr is None else lr)
+        self.optimizer_step(lr_at(self.steps_done, int(total_steps)) if lr is None else lr)
         return loss
+
+    def projector_state_dict(self) -> Dict[str, torch.Tensor]:
+        """the fp32 masters under the reference's checkpoint keys (`model.mm_projector.*`): k_proj / v_proj split out
+        of the engine's stacked cross-attention matrix, the cross-attention `in_proj_bias` = q | k | v concatenated."""
+        out = {}
+        for ref, (eng_name, rows) in _ref_to_engine(self.eng.cfg).items():
+            if isinstance(eng_name, tuple):
+                t = torch.cat([self.master(n).reshape(-1) for n in eng_name])
+            else:
+                t = self.master(eng_name)
+                t = t if rows is None else t[rows]
+            out["model.mm_projector." + ref] = t.detach().to("cpu", torch.float32).clone()
+        return out
+
+    def save_projector(self, path: str, dtype: torch.dtype = torch.bfloat16) -> str:
+        """write the reference's Stage-1 checkpoint: `mm_projector.bin`, a flat torch.save dict of the projector's parameters under
+        `model.mm_projector.*` keys (ref:vis_zephyr/train/vis_zephyr_trainer.py:304-348 saves `named_parameters()` filtered by
+        'mm_projector' in the training dtype, bf16; ref:vis_zephyr/model/builder.py:118-120 loads it with strict=False) - the file
+        `load_pretrained_model` of either implementation ingests.  `path` = the file, or a directory that receives mm_projector.bin."""
+        import os
+        if os.path.isdir(path):
+            path = os.path.join(path, "mm_projector.bin")
+        torch.save({k: v.to(dtype) for k, v in self.projector_state_dict().items()}, path)
+        return path
 
     def init_comm(self):
         """data-parallel communicator (RCCL) over torch.distributed's ranks: rank 0's unique id travels over the process group."""
