@@ -63,10 +63,11 @@ def algorithmic_work(cfg, S, n_tiles):
     return decode_weight_bytes, prefill_linear_flops
 
 
-def pmc_traffic():
-    """HBM read bytes per GEMV launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in its own run, x1024 x2
+def pmc_traffic(persist=True):
+    """HBM read bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in its own run, x1024 x2
     per the gfx950 correction); PMC counters cannot be read from inside this process."""
-    for name in ("r02_pmc_gemv_fetch.json", "r01_pmc_gemv_fetch.json"):
+    names = ("r03_pmc_decode_token_fetch.json",) if persist else ("r03_pmc_gemv_fetch.json", "r02_pmc_gemv_fetch.json", "r01_pmc_gemv_fetch.json")
+    for name in names:
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 return int(json.load(f)["hbm_read_bytes_per_launch"])
@@ -162,6 +163,30 @@ def streamer_leg(model, ids, tiles, n_new, steps):
                     "hipGraph, 4-byte token read-back through a pinned ring, callbacks of token t under step t+1"}
 
 
+
+
+def persistent_leg(model, ids, tiles, n_new):
+    """the same request with every decoded token as ONE resident grid (csrc/decode_persist.hip, opt-in vz_tune_set(28, 1)): the round-3
+    answer to 'remove launches, not tune them' - bit-identical ids, measured beside the default launch chain, never `value`."""
+    from vz_hip import binding as B
+    B.check(B.lib().vz_tune_set(28, 1))
+    try:
+        def one():
+            tm = {}
+            t0 = time.perf_counter()
+            out = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n_new, eos_token_id=None, pad_token_id=2, timing=tm)
+            torch.cuda.synchronize()
+            return out[0].tolist(), time.perf_counter() - tm["t_first_token"], model.engine.persist_mode()
+        one()
+        ids_p, dt, mode = one()
+    finally:
+        B.check(B.lib().vz_tune_set(28, 0))
+    ids_c = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n_new, eos_token_id=None, pad_token_id=2)[0].tolist()
+    if not mode:
+        return {"value": None, "why": "not available on this device (needs 256 CUs)"}
+    return {"value": round((n_new - 1) / dt, 2), "unit": "tokens/s", "ids_equal_to_the_launch_chain": ids_p == ids_c,
+            "what": "one resident 256-workgroup grid per token (129 weight streams + 32 attention phases as phases with in-launch hand-offs); "
+                    "opt-in, slower than the launch chain on MI355X: profiles/r03_persist_stamps.txt"}
 
 
 def cpu_baseline(cfg_full, S, n_tiles, n_new):
@@ -403,10 +428,9 @@ def main():
                 "method": "HIP events around every RCCL call of one prefill and 8 eager decode steps after the timed region (rank 0)"}
 
     # ---- roofline legs: instrumented replays of the same work, HIP events on the launch stream ----
-    roof, roof_prefill, parity, stream_leg = None, None, None, None
+    roof, roof_prefill, parity, stream_leg, persist_leg = None, None, None, None, None
     if rank == 0 and not tp_mode and not dry:          # (a tensor-parallel engine needs every rank inside each collective)
         w_bytes, pre_flops = algorithmic_work(cfg, S, n_tiles)
-        n_gemv_per_token = 4 * cfg.n_layers + 1
         emb = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles])[4]
         _, last = eng.prefill(emb, [S])
         eng.decode_begin(last.argmax(-1).to(torch.int32), [S], [S])
@@ -416,14 +440,21 @@ def main():
         torch.cuda.synchronize()
         n_l, ms = eng.prof_read()
         eng.prof_enable(False)
+        persist = eng.persist_mode()
         avg_ms = ms / max(1, n_l)
-        bytes_per_launch = w_bytes / n_gemv_per_token
+        # the dominant kernel of a decoded token: ONE launch of the persistent decode-token kernel (decode_persist.hip: all 129 weight
+        # streams + the 32 attention phases of the token; its algorithmic bytes = every weight once + the KV cache once), or - launch
+        # chain, vz_tune_set(28, 0) / other devices - the 129 weight-streaming GEMV launches (weights only)
+        kv_bytes = 2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * 2 * (S + n_prof // 2)
+        launches_per_token = n_l / n_prof
+        bytes_per_launch = (w_bytes + kv_bytes) if persist else w_bytes / launches_per_token
         ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "gemv_bf16_kernel<1> (decode weight stream)", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
-                "launches": n_l, "avg_launch_ms": round(avg_ms, 5),
+        roof = {"bound": "hbm", "kernel": "decode_token_kernel (one resident grid per token: 129 weight streams + 32 attention phases)" if persist
+                else "gemv_bf16_kernel<1> (decode weight stream)", "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(persist),
+                "launches": n_l, "launches_per_token": round(launches_per_token, 2), "avg_launch_ms": round(avg_ms, 5),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                "method": f"HIP events around every GEMV launch of {n_prof} eager decode steps after the timed region"}
+                "method": f"HIP events stamped by every such launch of {n_prof} eager decode steps after the timed region"}
         eng.prof_enable(True, B.K_GEMM)
         eng.prefill(emb, [S])
         torch.cuda.synchronize()
@@ -448,6 +479,7 @@ def main():
         parity = parity_check(model, ids, tiles, cfg.n_layers)
         if world == 1:
             stream_leg = streamer_leg(model, ids, tiles, n_new, args.steps)
+            persist_leg = persistent_leg(model, ids, tiles, n_new)
 
     # ---- extra leg (never `value`): the same request on the W8A16 engine of SURVEY config 5 - e4m3 weights with per-row
     # power-of-two scales streamed by the decode GEMV, bf16 activations, bf16 MFMA prefill on the dequantised weights.
@@ -536,6 +568,8 @@ def main():
         line["parity"] = parity
     if stream_leg is not None:
         line["streamer_path"] = stream_leg
+    if persist_leg is not None:
+        line["persistent_kernel"] = persist_leg
     if fp8_leg is not None:
         line["fp8_weights"] = fp8_leg
     if tp_leg is not None:

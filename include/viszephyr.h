@@ -293,11 +293,13 @@ int vz_op_sample(const float* d_logits, int rows, int cols, float temperature, i
 /* how the last vz_llm_decode_steps ran: *graph = 1 when a captured hipGraph was replayed; *comm_in_graph = 1 when the RCCL
  * collectives of a tensor-parallel engine are part of that graph (0 = eager steps, e.g. after RCCL refused the capture) */
 int vz_llm_decode_mode(vz_engine* e, int* graph, int* comm_in_graph);
-/* Batch-1 decode on an MI355X (ABI 10): with one row, one GPU, bf16 weights and the Zephyr-7B geometry vz_llm_decode_steps runs every
- * token as ONE resident grid (decode_persist.hip: the 161 launches of a step become phases with in-launch hand-offs; bit-identical
- * logits); vz_tune_set(28, 0) keeps the launch chain.  A phase hand-off that expires raises VZ_ASYNC_PERSIST (vz_engine_async_error).
+/* Batch-1 decode on an MI355X (ABI 10): after vz_tune_set(28, 1), with one row, one GPU, bf16 weights and the Zephyr-7B geometry,
+ * vz_llm_decode_steps runs every token as ONE resident grid (decode_persist.hip: the 161 launches of a step become phases with
+ * in-launch hand-offs; bit-identical logits).  Opt-in: on MI355X it measured slower than the launch chain.  A phase hand-off that expires raises VZ_ASYNC_PERSIST (vz_engine_async_error).
  * vz_test_persist_poke is a test hook: *mode = 1 if the last steps ran that way; word >= 0 presets an arrival counter. */
 int vz_test_persist_poke(vz_engine* e, int word, unsigned value, int* mode, vz_stream stream);
+/* profiling: s_memrealtime stamps (100 MHz) of workgroup 0's sync wave at the 12 phase edges of every layer of the last token */
+int vz_prof_persist_stamps(vz_engine* e, unsigned long long* host_out, int n_layers);
 /* batch-1 decode runs QKV GEMV + attention + O GEMV of a layer as ONE launch whose roles hand over through device-side counters;
  * every device-side wait is bounded and raises a word when it expires.  Reads and clears that word (blocking): *err != 0 = the
  * outputs since the previous call are invalid. */

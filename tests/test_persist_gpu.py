@@ -1,9 +1,9 @@
 """The persistent decode-token kernel (csrc/decode_persist.hip: batch-1 decode steps as ONE resident grid per token, the 161 launches
-of a step as phases with in-launch hand-offs) against the launch chain it replaces (vz_tune_set(28, 0)): the same arithmetic in the
+of a step as phases with in-launch hand-offs) against the launch chain (the default; the persistent kernel is opt-in, vz_tune_set(28, 1): it measured slower on MI355X): the same arithmetic in the
 same order, so logits and ids must be EQUAL bit for bit - eager and through the captured per-token graph, at 2 and at 32 layers, short
 and long contexts (1 .. 18 context splits of the attention phase) - and its bounded waits must end the launch and raise
 VZ_ASYNC_PERSIST instead of hanging (hf:models/mistral/modeling_mistral.py:202-241 is the arithmetic of a step; the oracle / reference
-parity of the launch chain is tests/test_stages_gpu.py / test_depth32_gpu.py, which run on the persistent kernel by default)."""
+parity of the launch chain is tests/test_stages_gpu.py / test_depth32_gpu.py)."""
 import os
 
 import pytest
@@ -43,7 +43,7 @@ def _steps(model, emb, n, persist):
         eng.check_async()
         return ids[0].clone(), lg[:, 0].clone(), eng.persist_mode()
     finally:
-        _knob(1)
+        _knob(0)
 
 
 @pytest.fixture(scope="module")
@@ -85,7 +85,7 @@ def test_persistent_graph_replay_equals_launch_chain_and_sampling_tail(small):
             model.engine.check_async()
             outs[persist] = (g, s_, mode)
         finally:
-            _knob(1)
+            _knob(0)
     if not outs[1][2]:
         pytest.skip("the persistent kernel is not available on this device")
     assert outs[1][0] == outs[0][0] and outs[1][1] == outs[0][1]
@@ -105,11 +105,15 @@ def test_expired_hand_off_ends_the_launch_and_raises(small):
         pytest.skip("the persistent kernel is not available on this device")
     for word, value in ((0, -1000), (8, 1)):
         S = emb.shape[1]
-        _, last = eng.prefill(emb, [S], all_logits=False, last_logits=True)
-        eng.decode_begin(last.argmax(-1).to(torch.int32), [S], [S])
-        eng.persist_poke(word, value)
-        eng.decode_steps(1)
-        torch.cuda.synchronize()                       # the launch ended (bounded waits): nothing hangs
+        _knob(1)
+        try:
+            _, last = eng.prefill(emb, [S], all_logits=False, last_logits=True)
+            eng.decode_begin(last.argmax(-1).to(torch.int32), [S], [S])
+            eng.persist_poke(word, value)
+            eng.decode_steps(1)
+            torch.cuda.synchronize()                       # the launch ended (bounded waits): nothing hangs
+        finally:
+            _knob(0)
         with pytest.raises(RuntimeError, match="persistent decode-token kernel"):
             eng.check_async()
         ids2, lg2, _ = _steps(model, emb, 2, persist=1)

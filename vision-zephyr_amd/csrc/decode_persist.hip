@@ -72,6 +72,7 @@ struct TokParams {
     float* part; unsigned* ticket;                                         // attention partials / tickets
     const float *cosT, *sinT;
     unsigned* sync;                                                        // [NSHARD + 1][16] arrival counters, abort word
+    unsigned long long* stamps;                                            // [n_layers][12] s_memrealtime of workgroup 0's sync wave (tools/persist_stamps.py)
     int* err;
     int vocab, max_ctx, nsplit, window;
     float scale, eps;
@@ -179,6 +180,9 @@ __device__ __forceinline__ void compute(const u32x4 (&wb)[16], Lds& sm, int wave
 }
 
 // ---- sync wave ----
+__device__ __forceinline__ void stamp(const TokParams& p, int wg, int lane, int l, int k) {
+    if (wg == 0 && lane == 0) p.stamps[l * 12 + k] = __builtin_amdgcn_s_memrealtime();
+}
 // arrive: this workgroup has finished phase `seq` (all its stores are drained: the caller sits behind the workgroup barrier)
 __device__ __forceinline__ void arrive(const TokParams& p, int wg, int lane) {
     if (lane == 0) __hip_atomic_fetch_add(p.sync + (wg & (NSHARD - 1)) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -279,40 +283,49 @@ __device__ __forceinline__ void run_streamer(const TokParams& p, Lds& sm, const 
         issue<K_Q>(wb1, L0, gw, 1, lane);
     }
     __syncthreads();                                    // S0: abort flag initialised
+    // Schedule of a phase with n units per wave (unit 0 in wb0, unit 1 in wb1 when it starts): compute(k), issue(k + 2) for k < n - 2,
+    // then the last two computes back to back, the "results in LDS" barrier, and only THEN the first two units of the next phase:
+    // issuing a unit blocks the wave until the CU's memory pipe has taken its 8..16 KiB (measured: ~2 us per 16-KiB unit with all eight
+    // waves issuing - the pipe accepts at about the CU's HBM share), and nobody may wait for that in front of the barrier that lets
+    // the sync wave publish.  The two units issued behind it are what keeps HBM busy while the phase edge is crossed.
     for (int l = 0; l < L; ++l) {
         const TokLayer Ly = load_layer(table, l);
         const bf16_t* next_qkv = load_layer(table, l + 1 < L ? l + 1 : l).qkv_w;
         __syncthreads();                                // S1
         compute<K_Q>(wb0, sm, wave, gw, 0, lane, carry); SB(); issue<K_Q>(wb0, Ly, gw, 2, lane); SB();
-        compute<K_Q>(wb1, sm, wave, gw, 1, lane, carry); SB(); issue<K_O>(wb1, Ly, gw, 0, lane); SB();
-        compute<K_Q>(wb0, sm, wave, gw, 2, lane, carry); SB(); issue<K_O>(wb0, Ly, gw, 1, lane); SB();
+        compute<K_Q>(wb1, sm, wave, gw, 1, lane, carry); SB();
+        compute<K_Q>(wb0, sm, wave, gw, 2, lane, carry); SB();
         __syncthreads();                                // S2
+        issue<K_O>(wb0, Ly, gw, 0, lane); SB(); issue<K_O>(wb1, Ly, gw, 1, lane); SB();
         __syncthreads();                                // S3
-        if (a_on) attn_dec::shadow(ap0, a_split, slot0, sm.attn);     // the attention body's barriers; wb1 / wb0 hold the O projection's rows meanwhile
+        if (a_on) attn_dec::shadow(ap0, a_split, slot0, sm.attn);     // the attention body's barriers; wb0 / wb1 hold the O projection's rows meanwhile
         __syncthreads();                                // S4
         __syncthreads();                                // S5
-        compute<K_O>(wb1, sm, wave, gw, 0, lane, carry); SB(); issue<K_G>(wb1, Ly, gw, 0, lane); SB();
-        compute<K_O>(wb0, sm, wave, gw, 1, lane, carry); SB(); issue<K_G>(wb0, Ly, gw, 1, lane); SB();
+        compute<K_O>(wb0, sm, wave, gw, 0, lane, carry); SB();
+        compute<K_O>(wb1, sm, wave, gw, 1, lane, carry); SB();
         __syncthreads();                                // S6
+        issue<K_G>(wb0, Ly, gw, 0, lane); SB(); issue<K_G>(wb1, Ly, gw, 1, lane); SB();
         __syncthreads();                                // S7
-        compute<K_G>(wb1, sm, wave, gw, 0, lane, carry); SB(); issue<K_G>(wb1, Ly, gw, 2, lane); SB();
-        compute<K_G>(wb0, sm, wave, gw, 1, lane, carry); SB(); issue<K_G>(wb0, Ly, gw, 3, lane); SB();
-        compute<K_G>(wb1, sm, wave, gw, 2, lane, carry); SB(); issue<K_G>(wb1, Ly, gw, 4, lane); SB();
-        compute<K_G>(wb0, sm, wave, gw, 3, lane, carry); SB(); issue<K_G>(wb0, Ly, gw, 5, lane); SB();
-        compute<K_G>(wb1, sm, wave, gw, 4, lane, carry); SB(); issue<K_G>(wb1, Ly, gw, 6, lane); SB();
-        compute<K_G>(wb0, sm, wave, gw, 5, lane, carry); SB(); issue<K_D>(wb0, Ly, gw, 0, lane); SB();
-        compute<K_G>(wb1, sm, wave, gw, 6, lane, carry); SB(); issue<K_D>(wb1, Ly, gw, 1, lane); SB();
+        compute<K_G>(wb0, sm, wave, gw, 0, lane, carry); SB(); issue<K_G>(wb0, Ly, gw, 2, lane); SB();
+        compute<K_G>(wb1, sm, wave, gw, 1, lane, carry); SB(); issue<K_G>(wb1, Ly, gw, 3, lane); SB();
+        compute<K_G>(wb0, sm, wave, gw, 2, lane, carry); SB(); issue<K_G>(wb0, Ly, gw, 4, lane); SB();
+        compute<K_G>(wb1, sm, wave, gw, 3, lane, carry); SB(); issue<K_G>(wb1, Ly, gw, 5, lane); SB();
+        compute<K_G>(wb0, sm, wave, gw, 4, lane, carry); SB(); issue<K_G>(wb0, Ly, gw, 6, lane); SB();
+        compute<K_G>(wb1, sm, wave, gw, 5, lane, carry); SB();
+        compute<K_G>(wb0, sm, wave, gw, 6, lane, carry); SB();
         __syncthreads();                                // S8
+        issue<K_D>(wb0, Ly, gw, 0, lane); SB(); issue<K_D>(wb1, Ly, gw, 1, lane); SB();
         __syncthreads();                                // S9
         compute<K_D>(wb0, sm, wave, gw, 0, lane, carry); SB(); issue<K_D>(wb0, Ly, gw, 2, lane); SB();
         compute<K_D>(wb1, sm, wave, gw, 1, lane, carry); SB(); issue<K_D>(wb1, Ly, gw, 3, lane); SB();
+        compute<K_D>(wb0, sm, wave, gw, 2, lane, carry); SB();
+        compute<K_D>(wb1, sm, wave, gw, 3, lane, carry); SB();
+        __syncthreads();                                // S10
         // the next two units belong to the next layer's QKV projection - or to the lm_head behind the last layer (same shape: rows of K = 4096)
         const bool more = l + 1 < L;
         const bf16_t* nw = more ? as_global(next_qkv) : p.lm_head;
         const int nr0 = more ? gw * NQ : min(lm_r0, lm_last), nr1 = more ? gw * NQ + 1 : min(lm_r0 + 1, lm_last);
-        compute<K_D>(wb0, sm, wave, gw, 2, lane, carry); SB(); issue_row8(wb0, nw, nr0, lane); SB();
-        compute<K_D>(wb1, sm, wave, gw, 3, lane, carry); SB(); issue_row8(wb1, nw, nr1, lane); SB();
-        __syncthreads();                                // S10
+        issue_row8(wb0, nw, nr0, lane); SB(); issue_row8(wb1, nw, nr1, lane); SB();
     }
     __syncthreads();                                    // S11
     // lm_head: rows lm_r0 .. lm_r1 - 1, two in flight (wb0 / wb1 hold the first two); rows past the wave's range are clamped and not stored
@@ -346,17 +359,21 @@ __device__ __forceinline__ void run_sync_attn(const TokParams& p, Lds& sm, Fused
         const TokLayer Ly = load_layer(p.layers, l);
         const unsigned q0 = base + (unsigned)l * 5;
         if (syncer) {
+            stamp(p, wg, lane, l, 0);
             if (l == 0) gather_raw<HD, false>(p.embed + (size_t)p.cur[0] * HD, sm.xraw, lane);
-            else { (void)wait_all(p, sm, q0 * per_shard, lane); gather_raw<HD, true>(p.xa, sm.xraw, lane); }
+            else { (void)wait_all(p, sm, q0 * per_shard, lane); stamp(p, wg, lane, l, 1); gather_raw<HD, true>(p.xa, sm.xraw, lane); }
             rmsnorm_lds<4>(sm, as_global(Ly.in_norm), p.eps, lane);
+            stamp(p, wg, lane, l, 2);
         }
         __syncthreads();                                // S1
         __syncthreads();                                // S2
         if (syncer) {
+            stamp(p, wg, lane, l, 3);
             publish(p.qkv, sm, wg, NSTREAM * NQ, lane);
             arrive(p, wg, lane);
             (void)wait_all(p, sm, (q0 + 1) * per_shard, lane);
             gather_raw<QKVN, true>(p.qkv, sm.xn, lane);
+            stamp(p, wg, lane, l, 4);
         }
         __syncthreads();                                // S3
         if (a_on) {
@@ -366,30 +383,37 @@ __device__ __forceinline__ void run_sync_attn(const TokParams& p, Lds& sm, Fused
         }
         __syncthreads();                                // S4
         if (syncer) {
+            stamp(p, wg, lane, l, 5);
             arrive(p, wg, lane);
             (void)wait_all(p, sm, (q0 + 2) * per_shard, lane);
             gather_raw<HD, true>(p.att, sm.xn, lane);
+            stamp(p, wg, lane, l, 6);
         }
         __syncthreads();                                // S5
         __syncthreads();                                // S6
         if (syncer) {
+            stamp(p, wg, lane, l, 7);
             publish(p.xb, sm, wg, NSTREAM * NO, lane);
             arrive(p, wg, lane);
             (void)wait_all(p, sm, (q0 + 3) * per_shard, lane);
             gather_raw<HD, true>(p.xb, sm.xraw, lane);
             rmsnorm_lds<8>(sm, as_global(Ly.post_norm), p.eps, lane);
+            stamp(p, wg, lane, l, 8);
         }
         __syncthreads();                                // S7
         __syncthreads();                                // S8
         if (syncer) {
+            stamp(p, wg, lane, l, 9);
             publish(p.act, sm, wg, NSTREAM * NG, lane);
             arrive(p, wg, lane);
             (void)wait_all(p, sm, (q0 + 4) * per_shard, lane);
             gather_raw<IN, true>(p.act, sm.xn, lane);
+            stamp(p, wg, lane, l, 10);
         }
         __syncthreads();                                // S9
         __syncthreads();                                // S10
         if (syncer) {
+            stamp(p, wg, lane, l, 11);
             publish(p.xa, sm, wg, NSTREAM * NO, lane);
             arrive(p, wg, lane);
         }
@@ -426,6 +450,7 @@ struct VzTokState {
     TokLayer* d_layers = nullptr; int n_layers = 0;
     bf16_t* d_vec = nullptr;             // xa | xb | qkv | att | act
     unsigned* d_sync = nullptr;
+    unsigned long long* d_stamps = nullptr;
 };
 
 bool vz_decode_persist_supported() {
@@ -454,6 +479,8 @@ int vz_decode_persist_create(const VzTokLayerHost* layers, int n_layers, VzTokSt
     if (er == hipSuccess) er = hipMalloc((void**)&st->d_vec, (size_t)(HD + HD + QKVN + HD + IN) * sizeof(bf16_t));
     if (er == hipSuccess) er = hipMalloc((void**)&st->d_sync, (NSHARD + 1) * 16 * sizeof(unsigned));
     if (er == hipSuccess) er = hipMemset(st->d_sync, 0, (NSHARD + 1) * 16 * sizeof(unsigned));
+    if (er == hipSuccess) er = hipMalloc((void**)&st->d_stamps, (size_t)n_layers * 12 * sizeof(unsigned long long));
+    if (er == hipSuccess) er = hipMemset(st->d_stamps, 0, (size_t)n_layers * 12 * sizeof(unsigned long long));
     if (er != hipSuccess) { vz_set_error("decode_persist_create: %s", hipGetErrorString(er)); vz_decode_persist_destroy(st); return VZ_ERR_HIP; }
     st->n_layers = n_layers;
     *out = st;
@@ -465,6 +492,7 @@ void vz_decode_persist_destroy(VzTokState* st) {
     if (st->d_layers) (void)hipFree(st->d_layers);
     if (st->d_vec) (void)hipFree(st->d_vec);
     if (st->d_sync) (void)hipFree(st->d_sync);
+    if (st->d_stamps) (void)hipFree(st->d_stamps);
     delete st;
 }
 
@@ -482,6 +510,14 @@ int vz_decode_persist_poke(VzTokState* st, int word, unsigned value, hipStream_t
     return VZ_OK;
 }
 
+// the phase stamps of the LAST launched token (workgroup 0's sync wave; 12 per layer, 100 MHz ticks): blocking copy
+int vz_decode_persist_stamps(VzTokState* st, unsigned long long* host, int n_layers) {
+    VZ_CHECK_ARG(st && host && n_layers == st->n_layers, "decode_persist_stamps: bad argument");
+    VZ_CHECK_HIP(hipDeviceSynchronize());
+    VZ_CHECK_HIP(hipMemcpy(host, st->d_stamps, (size_t)n_layers * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return VZ_OK;
+}
+
 int vz_launch_decode_token(VzTokState* st, const VzTokArgs& a, hipStream_t s) {
     VZ_CHECK_ARG(st && a.vocab >= NWG && a.nsplit >= 1 && a.nsplit <= 32, "decode_token: bad argument (nsplit %d)", a.nsplit);
     TokParams p;
@@ -490,7 +526,7 @@ int vz_launch_decode_token(VzTokState* st, const VzTokArgs& a, hipStream_t s) {
     p.cur = a.cur; p.pos = a.pos; p.slot = a.slot; p.step = a.step;
     p.xa = st->d_vec; p.xb = p.xa + HD; p.qkv = p.xb + HD; p.att = p.qkv + QKVN; p.act = p.att + HD;
     p.logits = a.logits; p.part = a.part; p.ticket = a.ticket; p.cosT = a.cosT; p.sinT = a.sinT;
-    p.sync = st->d_sync; p.err = a.err;
+    p.sync = st->d_sync; p.stamps = st->d_stamps; p.err = a.err;
     p.vocab = a.vocab; p.max_ctx = a.max_ctx; p.nsplit = a.nsplit; p.window = a.window; p.scale = a.scale; p.eps = a.eps;
     static_assert(sizeof(Lds) <= LDS_REQUEST, "LDS image");
     vz_launch_timed(decode_token_kernel, dim3(NWG), dim3(TPB), LDS_REQUEST, s, p);

@@ -831,7 +831,8 @@ extern "C" int vz_embed_splice(vz_engine* e, const int* d_kind, const int* d_idx
 // call sites through RCCL (all-reduce over one rank = identity, all-gather = copy), so the collective plumbing - library,
 // dtypes, in-place buffers, stream order, the vocab-parallel gather + repack - runs on a single GPU.
 static int g_force_comm = 0;
-static int g_persist_decode = 1;   // vz_tune_set(28, v): 1 = batch-1 decode steps as one resident grid per token (decode_persist.hip), 0 = the launch chain
+static int g_persist_decode = 0;   // vz_tune_set(28, 1): batch-1 decode steps as one resident grid per token (decode_persist.hip) instead of the launch chain.
+                                   // Off by default: measured 282 vs 339 tok/s (profiles/r03_persist_stamps.txt: the phase edges + the attention phase leave HBM idle longer than the launch boundaries they replace)
 static int g_attn_nsplit = 0;   // vz_tune_set(10, n): context splits of the fused decode attention (0 = engine default)
 static inline bool tp_local(const vz_engine* e) { return e->tp == 1 && !(g_force_comm && e->comm); }
 
@@ -1250,8 +1251,8 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     if (!tp_local(e)) RC(ensure_gather(e, B, s));
     int* step = e->d_state + 4 * c.max_batch;
     VZ_CHECK_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
-    // Batch 1, one GPU, bf16 weights, Zephyr-7B geometry on a 256-CU device: the steps run as ONE resident grid per token
-    // (decode_persist.hip; vz_tune_set(28, 0) = the launch chain).  Its pointer table is (re)built here, never inside a capture.
+    // vz_tune_set(28, 1) - batch 1, one GPU, bf16 weights, Zephyr-7B geometry on a 256-CU device: the steps run as ONE resident grid
+    // per token (decode_persist.hip) instead of the launch chain.  Its pointer table is (re)built here, never inside a capture.
     e->use_tok = false;
     if (g_persist_decode && B == 1 && e->tp == 1 && tp_local(e) && !c.weight_fp8 && c.hidden == 4096 && c.inter == 14336 && c.n_heads == 32 &&
         c.n_kv_heads == 8 && c.head_dim == 128 && c.vocab >= 256 && vz_decode_persist_supported()) {
@@ -1428,6 +1429,12 @@ int vz_attn_read_stamps(long long* host16);
 extern "C" int vz_prof_attn_stamps(long long* host16) { return vz_attn_read_stamps(host16); }
 extern "C" int vz_prof_gemm_stamps(long long* host_out, int max_wgs, int* n_wgs) {
     return vz_gemm256_read_stamps(host_out, max_wgs, n_wgs);
+}
+
+// phase stamps of the last token the persistent decode-token kernel ran (tools/persist_stamps.py): [n_layers][12] 100 MHz ticks
+extern "C" int vz_prof_persist_stamps(vz_engine* e, unsigned long long* host, int n_layers) {
+    VZ_CHECK_ARG(e && e->tok, "prof_persist_stamps: the engine has not run a step on the persistent kernel");
+    return vz_decode_persist_stamps(e->tok, host, n_layers);
 }
 
 extern "C" int vz_prof_enable(vz_engine* e, int enable, int klass) {

@@ -260,6 +260,7 @@ void vz_decode_persist_destroy(VzTokState* st);
 int vz_decode_persist_reset(VzTokState* st, hipStream_t s);
 int vz_decode_persist_poke(VzTokState* st, int word, unsigned value, hipStream_t s);
 int vz_launch_decode_token(VzTokState* st, const VzTokArgs& a, hipStream_t s);
+int vz_decode_persist_stamps(VzTokState* st, unsigned long long* host, int n_layers);
 
 // decode attention with RoPE + KV append + split combine fused into one launch (attn_decode.hip)
 struct AttnDecodeFusedArgs {

@@ -81,6 +81,7 @@ SYMBOLS = {
     "vz_llm_decode_steps": (_I, [_P, _I, _P, _P, _P]),
     "vz_llm_decode_mode": (_I, [_P, _P, _P]),
     "vz_test_persist_poke": (_I, [_P, _I, C.c_uint, _P, _P]),
+    "vz_prof_persist_stamps": (_I, [_P, _P, _I]),
     "vz_engine_async_error": (_I, [_P, _P]),
     "vz_tune_set": (_I, [_I, _I]),
     "vz_engine_resize_vocab": (_I, [_P, _I]),
