@@ -228,12 +228,49 @@ def cpu_baseline(cfg_full, S, n_tiles, n_new):
     t_layer_dec = max(1e-9, (t_dec2 - t_head) / 2)
     tok_s = 1.0 / (cfg_full.n_layers * t_layer_dec + t_head)
     ttft = n_tiles * (t_clip + t_qf) + cfg_full.n_layers * (t_pre1 - t_head) + t_head
+    measured = None
+    try:
+        measured = cpu_measured_c1(cfg_full, dev)
+    except Exception as ex:      # (host memory: the full fp32 model is 36 GB)
+        measured = {"error": f"{type(ex).__name__}: {ex}"}
     return {"value": round(tok_s, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
-            "image_to_first_token_ms": round(ttft * 1e3, 1),
+            "image_to_first_token_ms": round(ttft * 1e3, 1), "measured_c1": measured,
             "sample": f"oracle fp32 on {threads} host threads ({os.cpu_count()} logical cpus): 1 CLIP tile {t_clip:.2f}s, "
                       f"1 Q-Former tile at L={L} {t_qf:.2f}s, 1 decoder layer prefill at S={S} {t_pre1:.2f}s, "
                       f"{n_dec} decode tokens over 2 layers at ctx {S} {t_dec2 * 1e3:.0f} ms/token, lm_head {t_head * 1e3:.0f} ms; "
                       f"scaled to {n_tiles} tiles / {cfg_full.n_layers} layers (weights generated in {t_w:.0f}s, untimed)"}
+
+
+def cpu_measured_c1(cfg_full, dev):
+    """MEASURED, not scaled: BASELINE configs[0] (the reference's own CPU-runnable case: 3 anyres tiles + 32-id prompt -> S = 127, fp32)
+    through the oracle with ALL decoder layers on this box's host cores - image->first-token and 8 greedy decode tokens against the KV
+    cache.  The configs[2] figure above is extrapolated from per-layer / per-tile samples (a full S = 2048 fp32 pass takes minutes);
+    this one calibrates it."""
+    from oracle import vz_oracle as O
+    from vz_hip import synth
+    t0 = time.perf_counter()
+    sd = {k: v.cpu() for k, v in synth.iter_state_dict(cfg_full, 0, device=dev)}
+    t_w = time.perf_counter() - t0
+    tiles = synth.synth_tiles(3, seed=1)
+    ids = synth.synth_ids(32, cfg_full.vocab, image_pos=5, seed=2).unsqueeze(0)
+    t0 = time.perf_counter()
+    emb = O.prepare_inputs_labels_for_multimodal(cfg_full, sd, ids, None, None, None, None, [tiles])[4]
+    t_vis = time.perf_counter() - t0
+    logits, cache = O.llm_forward(cfg_full, sd, emb, last_only=True)
+    tok = logits[0, -1].argmax().view(1)
+    t_first = time.perf_counter() - t0
+    n_dec = 8
+    t1 = time.perf_counter()
+    for _ in range(n_dec):
+        x = O.embed_tokens(sd, tok, O.FP32).unsqueeze(0)
+        m = torch.ones(1, cache.k[0].shape[1] + 1, dtype=torch.bool)
+        logits, cache = O.llm_forward(cfg_full, sd, x, attention_mask=m, cache=cache, last_only=True)
+        tok = logits[0, -1].argmax().view(1)
+    t_dec = (time.perf_counter() - t1) / n_dec
+    del sd
+    return {"workload": f"configs[0]: 3 tiles + 32 ids -> S = {emb.shape[1]}, {cfg_full.n_layers} layers, fp32, {n_dec} decode tokens",
+            "image_to_first_token_ms": round(t_first * 1e3, 1), "vision_and_splice_ms": round(t_vis * 1e3, 1),
+            "decode_tokens_per_s": round(1.0 / t_dec, 3), "weights_generated_s": round(t_w, 1)}
 
 
 def fp8_leg_only(args):
@@ -425,7 +462,8 @@ def main():
                                       "algbw_GBps": round(pre_bytes / max(1e-9, ms_p / max(1, n_p) * 1e-3) / 1e9, 1)},
                 "decode_collectives": {"launches": n_d, "avg_us": round(ms_d / max(1, n_d) * 1e3, 2), "bytes": cfg.hidden * 2,
                                        "per_token_ms": round(ms_d / 8, 4)},
-                "method": "HIP events around every RCCL call of one prefill and 8 eager decode steps after the timed region (rank 0)"}
+                "decode_allreduce_kernel": "one-shot (csrc/comm_oneshot.hip, VZ_TP_ONESHOT=1)" if getattr(eng, "oneshot", False) else "RCCL ncclAllReduce",
+                "method": "HIP events around every collective of one prefill and 8 eager decode steps after the timed region (rank 0)"}
 
     # ---- roofline legs: instrumented replays of the same work, HIP events on the launch stream ----
     roof, roof_prefill, parity, stream_leg, persist_leg = None, None, None, None, None

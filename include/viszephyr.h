@@ -37,6 +37,7 @@ extern "C" {
 /* values of the async error word (vz_engine_async_error / vz_op_async_error): which bounded device-side wait expired */
 /* (1 was the hand-off of the one-launch batch-1 attention half, removed in round 2: it never beat the three kernels) */
 #define VZ_ASYNC_STREAMK 2    /* stream-K fix-up of the 256^2 GEMM: the tile was written as NaN, never as a sum of stale slots */
+#define VZ_ASYNC_ONESHOT 4    /* a peer's vector never arrived in the one-shot all-reduce (comm_oneshot.hip): the output was poisoned with NaN */
 #define VZ_ASYNC_PERSIST 3    /* a phase hand-off of the persistent decode-token kernel (decode_persist.hip) expired: that token's logits are garbage */
 
 typedef void* vz_stream;
@@ -298,6 +299,23 @@ int vz_llm_decode_mode(vz_engine* e, int* graph, int* comm_in_graph);
  * in-launch hand-offs; bit-identical logits).  Opt-in: on MI355X it measured slower than the launch chain.  A phase hand-off that expires raises VZ_ASYNC_PERSIST (vz_engine_async_error).
  * vz_test_persist_poke is a test hook: *mode = 1 if the last steps ran that way; word >= 0 presets an arrival counter. */
 int vz_test_persist_poke(vz_engine* e, int word, unsigned value, int* mode, vz_stream stream);
+/* One-shot all-reduce of the tensor-parallel decode step (ABI 10; comm_oneshot.hip): every rank stores its bf16 vector into every
+ * peer's receive area as 8-byte {two bf16, sequence tag} granules (system scope: over xGMI when the areas are peer-mapped) and sums the
+ * N vectors it finds in its own area in rank order - one store-and-poll round instead of a ring.  `d_areas[q]` = rank q's receive area
+ * (vz_op_oneshot_area_bytes(n_ranks, max_elems) bytes, zero-filled once; peer areas opened through hipIpc by the caller), `d_seq` = two
+ * device words {sequence number = 1, ticket = 0} (a zero-filled area carries tag 0 = "nothing yet", so the numbering starts at 1); the launch advances the sequence number itself, so it replays
+ * from a hipGraph.  An engine with tp_size > 1 uses it for its decode-step all-reduces after vz_comm_oneshot_attach (RCCL otherwise).
+ * Tested in one process (N areas on one GPU, N concurrent launches); unmeasured over xGMI - no multi-GPU box was available. */
+size_t vz_op_oneshot_area_bytes(int n_ranks, int max_elems);
+int vz_op_allreduce_oneshot(void* const* d_areas, int rank, int n_ranks, int max_elems, const void* d_in, void* d_out, int n, unsigned* d_seq,
+                            int* d_err, vz_stream stream);
+/* test form: all n_ranks ranks as slices of one grid (one process, one GPU); d_in / d_out / d_seq are arrays of n_ranks pointers */
+int vz_test_allreduce_oneshot_all(void* const* d_areas, int n_ranks, int max_elems, const void* const* d_in, void* const* d_out, int n,
+                                  unsigned* const* d_seq, int* d_err, vz_stream stream);
+/* engine side: this rank's receive area + sequence words (allocated on first call; out_area may be exported with hipIpcGetMemHandle),
+ * then the N areas in rank order (own included) - from then on the decode step's [B, hidden] all-reduces take the one-shot kernel */
+int vz_comm_oneshot_local(vz_engine* e, void** out_area, size_t* out_bytes);
+int vz_comm_oneshot_attach(vz_engine* e, void* const* d_areas, int n_ranks);
 /* profiling: s_memrealtime stamps (100 MHz) of workgroup 0's sync wave at the 12 phase edges of every layer of the last token */
 int vz_prof_persist_stamps(vz_engine* e, unsigned long long* host_out, int n_layers);
 /* batch-1 decode runs QKV GEMV + attention + O GEMV of a layer as ONE launch whose roles hand over through device-side counters;

@@ -219,6 +219,9 @@ struct vz_engine {
     // of the vocabulary (Vp = ceil(vocab / tp) rows of lm_head, zero padded); tp == 1: everything.
     int tp = 1, rank = 0, Hq_l = 0, Hkv_l = 0, I_l = 0, Vp = 0;
     ncclComm_t comm = nullptr;
+    // one-shot all-reduce of the decode step (comm_oneshot.hip): this rank's receive area, every rank's area (peer-mapped), sequence words
+    void* os_area = nullptr; void* os_areas[8] = {nullptr}; int os_ranks = 0; unsigned* os_seq = nullptr;
+    static constexpr int OS_MAX_ELEMS = 64 * 4096;       // up to 64 decode rows of hidden 4096
     float* d_gather = nullptr;     // [tp][rows][Vp] all-gathered logits before the repack
     size_t gather_floats = 0;
     std::unordered_map<std::string, Weight> w;
@@ -503,6 +506,8 @@ extern "C" int vz_engine_destroy(vz_engine* e) {
     if (e->d_gather) (void)hipFree(e->d_gather);
     vz_decode_persist_destroy(e->tok);
     if (e->comm) (void)ncclCommDestroy(e->comm);
+    if (e->os_area) (void)hipFree(e->os_area);
+    if (e->os_seq) (void)hipFree(e->os_seq);
     if (e->h_pinned) hipHostFree(e->h_pinned);
     delete e;
     return VZ_OK;
@@ -841,7 +846,12 @@ static inline bool tp_local(const vz_engine* e) { return e->tp == 1 && !(g_force
 // meaningless as logits, the point is that nothing on the local path rejects the shapes of tp 2 / 4 / 8.
 static inline bool tp_skip(const vz_engine* e) { return e->tp > 1 && g_force_comm == 2; }
 
-static int tp_allreduce_bf16(vz_engine* e, bf16_t* buf, size_t count, hipStream_t s) {
+static int g_oneshot = 1;        // vz_tune_set(29, 0): keep RCCL for the decode step's all-reduces although peer areas are attached
+static int tp_allreduce_bf16(vz_engine* e, bf16_t* buf, size_t count, hipStream_t s, bool decode = false) {
+    if (decode && g_oneshot && e->os_ranks == e->tp && e->tp > 1 && (int)count <= vz_engine::OS_MAX_ELEMS && (count & 1) == 0 && !tp_skip(e)) {
+        ProfScope ps(e, K_COMM, s);
+        return vz_launch_allreduce_oneshot(e->os_areas, e->rank, e->tp, vz_engine::OS_MAX_ELEMS, buf, buf, (int)count, e->os_seq, e->d_ferr, s);
+    }
     if (tp_local(e) || tp_skip(e)) return VZ_OK;
     if (!e->comm) { vz_set_error("tensor-parallel engine used before vz_comm_init"); return VZ_ERR_STATE; }
     ProfScope ps(e, K_COMM, s);
@@ -910,6 +920,38 @@ extern "C" int vz_comm_init(vz_engine* e, const char* id128) {
     memcpy(&id, id128, 128);
     ncclResult_t r = ncclCommInitRank(&e->comm, e->tp, id, e->rank);
     if (r != ncclSuccess) { e->comm = nullptr; vz_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r)); return VZ_ERR_HIP; }
+    return VZ_OK;
+}
+
+extern "C" size_t vz_op_oneshot_area_bytes(int n_ranks, int max_elems) { return vz_oneshot_area_bytes(n_ranks, max_elems); }
+extern "C" int vz_op_allreduce_oneshot(void* const* d_areas, int rank, int n_ranks, int max_elems, const void* d_in, void* d_out, int n, unsigned* d_seq,
+                                       int* d_err, vz_stream stream) {
+    return vz_launch_allreduce_oneshot(d_areas, rank, n_ranks, max_elems, (const bf16_t*)d_in, (bf16_t*)d_out, n, d_seq, d_err, (hipStream_t)stream);
+}
+// TEST FORM: the n_ranks ranks of one all-reduce as slices of ONE grid (one process, one GPU: co-resident whatever the stream / queue mapping)
+extern "C" int vz_test_allreduce_oneshot_all(void* const* d_areas, int n_ranks, int max_elems, const void* const* d_in, void* const* d_out, int n,
+                                             unsigned* const* d_seq, int* d_err, vz_stream stream) {
+    return vz_launch_allreduce_oneshot_all(d_areas, n_ranks, max_elems, (const bf16_t* const*)d_in, (bf16_t* const*)d_out, n, d_seq, d_err, (hipStream_t)stream);
+}
+extern "C" int vz_comm_oneshot_local(vz_engine* e, void** out_area, size_t* out_bytes) {
+    VZ_CHECK_ARG(e && out_area && out_bytes && e->tp >= 1, "comm_oneshot_local: bad argument");
+    const size_t bytes = vz_oneshot_area_bytes(e->tp, vz_engine::OS_MAX_ELEMS);
+    if (!e->os_area) {
+        VZ_CHECK_HIP(hipMalloc(&e->os_area, bytes));
+        VZ_CHECK_HIP(hipMemset(e->os_area, 0, bytes));
+        VZ_CHECK_HIP(hipMalloc((void**)&e->os_seq, 2 * sizeof(unsigned)));
+        const unsigned init[2] = {1u, 0u};                  // sequence numbers start at 1: a zero-filled area carries tag 0 = "nothing yet"
+        VZ_CHECK_HIP(hipMemcpy(e->os_seq, init, sizeof(init), hipMemcpyHostToDevice));
+    }
+    *out_area = e->os_area; *out_bytes = bytes;
+    return VZ_OK;
+}
+extern "C" int vz_comm_oneshot_attach(vz_engine* e, void* const* d_areas, int n_ranks) {
+    VZ_CHECK_ARG(e && d_areas && n_ranks == e->tp && n_ranks <= 8 && e->os_area, "comm_oneshot_attach: needs tp_size areas after vz_comm_oneshot_local");
+    VZ_CHECK_ARG(d_areas[e->rank] == e->os_area, "comm_oneshot_attach: area %d must be this rank's own", e->rank);
+    RC(drop_decode_graph(e));
+    for (int q = 0; q < n_ranks; ++q) { VZ_CHECK_ARG(d_areas[q], "comm_oneshot_attach: area %d missing", q); e->os_areas[q] = d_areas[q]; }
+    e->os_ranks = n_ranks;
     return VZ_OK;
 }
 
@@ -1166,12 +1208,12 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
             }
             RC(linear(e, 1, att, A, WB(p + "o.w", (long)H * A), A, x, H, B, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
                       W8(p + "o.w8", (long)H * A), WS(p + "o.ws", H)));
-            RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
+            RC(tp_allreduce_bf16(e, x, (size_t)B * H, s, true));
             RC(linear(e, 1, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps,
                       W8(p + "gu.w8", 2L * I * H), WS(p + "gu.ws", 2L * I)));
             RC(linear(e, 1, act, I, WB(p + "down.w", (long)I * H), I, x, H, B, H, I, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
                       W8(p + "down.w8", (long)I * H), WS(p + "down.ws", H)));
-            RC(tp_allreduce_bf16(e, x, (size_t)B * H, s));
+            RC(tp_allreduce_bf16(e, x, (size_t)B * H, s, true));
             if (rc) return rc;
         }
         RC(lm_head_logits(e, x, B, e->d_logits, s, WF("llm.norm", H)));
@@ -1417,6 +1459,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 25) { g_qf_kv_all = value; return VZ_OK; }
     if (knob == 27) { g_wide_fp8_splits = value; return VZ_OK; }
     if (knob == 28) { g_persist_decode = value; return VZ_OK; }
+    if (knob == 29) { g_oneshot = value; return VZ_OK; }
     if (knob == 26) { vz_set_splitk_mid(value); return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }

@@ -262,6 +262,13 @@ int vz_decode_persist_poke(VzTokState* st, int word, unsigned value, hipStream_t
 int vz_launch_decode_token(VzTokState* st, const VzTokArgs& a, hipStream_t s);
 int vz_decode_persist_stamps(VzTokState* st, unsigned long long* host, int n_layers);
 
+// comm_oneshot.hip: one-shot all-reduce of the tensor-parallel decode step (8-byte tagged granules into every peer's receive area)
+size_t vz_oneshot_area_bytes(int n_ranks, int max_elems);
+int vz_launch_allreduce_oneshot(void* const* areas, int rank, int n_ranks, int max_elems, const bf16_t* in, bf16_t* out, int n, unsigned* seq,
+                                int* err, hipStream_t s);
+int vz_launch_allreduce_oneshot_all(void* const* areas, int n_ranks, int max_elems, const bf16_t* const* in, bf16_t* const* out, int n,
+                                    unsigned* const* seq, int* err, hipStream_t s);
+
 // decode attention with RoPE + KV append + split combine fused into one launch (attn_decode.hip)
 struct AttnDecodeFusedArgs {
     const bf16_t* qkv;     // [B, (Hq+2Hkv)*D]

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libviszephyr_hip.so")
 VZ_OK, VZ_ERR_ARG, VZ_ERR_HIP, VZ_ERR_STATE, VZ_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 VZ_ASYNC_STREAMK = 2
 VZ_ASYNC_PERSIST = 3
+VZ_ASYNC_ONESHOT = 4
 ABI_VERSION = 10
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
 K_GEMM, K_GEMV, K_ATTN, K_ATTN_DEC, K_NORM, K_OTHER, K_FUSED, K_COMM = range(8)
@@ -82,6 +83,11 @@ SYMBOLS = {
     "vz_llm_decode_mode": (_I, [_P, _P, _P]),
     "vz_test_persist_poke": (_I, [_P, _I, C.c_uint, _P, _P]),
     "vz_prof_persist_stamps": (_I, [_P, _P, _I]),
+    "vz_op_oneshot_area_bytes": (C.c_size_t, [_I, _I]),
+    "vz_op_allreduce_oneshot": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "vz_test_allreduce_oneshot_all": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "vz_comm_oneshot_local": (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "vz_comm_oneshot_attach": (_I, [_P, _P, _I]),
     "vz_engine_async_error": (_I, [_P, _P]),
     "vz_tune_set": (_I, [_I, _I]),
     "vz_engine_resize_vocab": (_I, [_P, _I]),
@@ -204,6 +210,32 @@ def tile_weights(w: torch.Tensor) -> torch.Tensor:
     wt = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
     check(lib().vz_op_tile_weights(ptr(w), w.shape[0], w.shape[1], w.stride(0), ptr(wt), stream_ptr(w.device)))
     return wt
+
+
+def oneshot_area(n_ranks: int, max_elems: int, device) -> torch.Tensor:
+    """zero-filled receive area of ONE rank of the one-shot all-reduce (comm_oneshot.hip)"""
+    return torch.zeros(int(lib().vz_op_oneshot_area_bytes(n_ranks, max_elems)), dtype=torch.uint8, device=device)
+
+
+def oneshot_seq(device) -> torch.Tensor:
+    """the two device words {sequence number = 1, ticket = 0} of one rank"""
+    return torch.tensor([1, 0], dtype=torch.int32, device=device)
+
+
+def allreduce_oneshot(areas, rank: int, max_elems: int, x: torch.Tensor, out: torch.Tensor, seq: torch.Tensor, err: torch.Tensor, stream=None):
+    """rank `rank`'s launch of one all-reduce over len(areas) ranks (areas[q] = rank q's receive area); on torch's current stream"""
+    _need_cuda(x, out, seq, err, *areas)
+    arr = (C.c_void_p * len(areas))(*[a.data_ptr() for a in areas])
+    check(lib().vz_op_allreduce_oneshot(arr, rank, len(areas), max_elems, ptr(x), ptr(out), x.numel(), ptr(seq), ptr(err),
+                                        stream_ptr(x.device) if stream is None else stream))
+
+
+def allreduce_oneshot_all(areas, max_elems: int, xs, outs, seqs, err: torch.Tensor):
+    """TEST FORM: every rank of one all-reduce as a slice of ONE launch (one process, one GPU)"""
+    n = len(areas)
+    _need_cuda(err, *areas, *xs, *outs, *seqs)
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
+    check(lib().vz_test_allreduce_oneshot_all(arr(areas), n, max_elems, arr(xs), arr(outs), xs[0].numel(), arr(seqs), ptr(err), stream_ptr(err.device)))
 
 
 def tile_weights_fp8(w8: torch.Tensor) -> torch.Tensor:

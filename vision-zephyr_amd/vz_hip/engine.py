@@ -300,6 +300,48 @@ class Engine:
         box = [bytes(buf.raw)]
         dist.broadcast_object_list(box, src=0)
         B.check(self.lib.vz_comm_init(self.h, box[0]))
+        if os.environ.get("VZ_TP_ONESHOT", "0") == "1":
+            self.init_oneshot()
+
+    def init_oneshot(self) -> bool:
+        """Opt-in (VZ_TP_ONESHOT=1): the decode step's [B, hidden] all-reduces on the one-shot kernel (csrc/comm_oneshot.hip) instead of
+        RCCL - every rank's receive area is exported with hipIpcGetMemHandle, the handles travel over torch.distributed, the peers' areas
+        are opened with hipIpcOpenMemHandle (peer-mapped over xGMI) and handed to the engine in rank order.  Returns False (RCCL stays)
+        if any rank fails to map a peer.  UNMEASURED: no multi-GPU box has been available to the build; the kernel's protocol and
+        arithmetic are tested in one process (tests/test_oneshot_gpu.py), this wiring only by tests/test_tp_gloo.py's dry plan."""
+        import torch.distributed as dist
+        class IpcHandle(C.Structure):                            # hipIpcMemHandle_t: 64 opaque bytes, passed BY VALUE to hipIpcOpenMemHandle
+            _fields_ = [("reserved", C.c_char * 64)]
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipIpcGetMemHandle.argtypes = [C.POINTER(IpcHandle), C.c_void_p]
+        hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), IpcHandle, C.c_uint]
+        area, nbytes = C.c_void_p(), C.c_size_t()
+        B.check(self.lib.vz_comm_oneshot_local(self.h, C.byref(area), C.byref(nbytes)))
+        handle = IpcHandle()
+        ok = hip.hipIpcGetMemHandle(C.byref(handle), area) == 0
+        box = [None] * self.tp_size
+        dist.all_gather_object(box, (ok, bytes(C.string_at(C.byref(handle), 64))))
+        areas = (C.c_void_p * self.tp_size)()
+        good = all(o for o, _ in box)
+        if good:
+            for q, (_, h) in enumerate(box):
+                if q == self.tp_rank:
+                    areas[q] = area.value
+                    continue
+                peer = C.c_void_p()
+                hq = IpcHandle()
+                C.memmove(C.byref(hq), h, 64)
+                if hip.hipIpcOpenMemHandle(C.byref(peer), hq, 1) != 0:        # hipIpcMemLazyEnablePeerAccess
+                    good = False
+                    break
+                areas[q] = peer.value
+        flags = [None] * self.tp_size
+        dist.all_gather_object(flags, bool(good))
+        if not all(flags):
+            return False
+        B.check(self.lib.vz_comm_oneshot_attach(self.h, areas, self.tp_size))
+        self.oneshot = True
+        return True
 
     def resize_vocab(self, n: int):
         """grow (new rows = mean of the old ones, as vz_hip.weights.resize_vocab does at load time) or shrink the
