@@ -42,9 +42,22 @@ def batch(cfg):
     return ids, mask, lab, [tb0, tb1]
 
 
+def long_batch(cfg):
+    """one Stage-1 sample at the length the reference trains up to (ref:script/pretrain.sh:44 --model_max_length 2048 caps it): 5 anyres
+    tiles + a 900-id caption -> S = 899 + 160 = 1059 spliced rows; the attention backward of the frozen Zephyr layers runs at S > 1024"""
+    tiles = synth.synth_tiles(5, seed=13)
+    ids = synth.synth_ids(900, cfg.vocab, image_pos=1, seed=15).unsqueeze(0)
+    mask = torch.ones_like(ids)
+    lab = ids.clone()
+    lab[ids == O.IMAGE_TOKEN_INDEX] = O.IGNORE_INDEX
+    lab[:, :2] = O.IGNORE_INDEX
+    return ids, mask, lab, [tiles]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(PIN.REPO, "tests", "golden"))
+    ap.add_argument("--long", action="store_true", help="the S = 1059 sample (long_batch) -> stage1_long.npz instead of the padded batch of 2")
     args = ap.parse_args()
     cfg = synth.ArchConfig(n_layers=2)
     t0 = time.time()
@@ -52,7 +65,8 @@ def main():
         model = PIN.build_reference(cfg, tmp)
     sd = PIN.load_synth(model, cfg, 0)
     print(f"[pin-train] reference ready {time.time() - t0:.0f}s", flush=True)
-    ids, mask, lab, images = batch(cfg)
+    ids, mask, lab, images = long_batch(cfg) if args.long else batch(cfg)
+    tag = "stage1_long" if args.long else "stage1_step"
 
     # ---- the reference's Stage-1 step ----
     model.requires_grad_(False)
@@ -110,10 +124,10 @@ def main():
         s, stride = PIN.sub((par.detach() - p0) * 1e5)
         fx[f"adamw_delta_x1e5.{k}.sub"] = s
     print(f"[pin-train] AdamW (2 steps) matches torch.optim.AdamW on {len(picks[:3])} tensors", flush=True)
-    assert abs(T.lr_at(0, 1000) - 0.0) < 1e-12 and abs(T.lr_at(30, 1000) - 2e-5) < 1e-12 and T.lr_at(1000, 1000) < 1e-12
+    assert abs(T.lr_at(0, 1000) - 0.0) < 1e-12 and abs(T.lr_at(30, 1000) - 2e-3) < 1e-12 and T.lr_at(1000, 1000) < 1e-12
     os.makedirs(args.out, exist_ok=True)
-    np.savez_compressed(os.path.join(args.out, "stage1_step.npz"), **fx)
-    with open(os.path.join(args.out, "stage1_step.json"), "w") as f:
+    np.savez_compressed(os.path.join(args.out, tag + ".npz"), **fx)
+    with open(os.path.join(args.out, tag + ".json"), "w") as f:
         json.dump(report, f, indent=1)
     print(f"[pin-train] OK - fixtures written ({time.time() - t0:.0f}s)", flush=True)
 

@@ -1,8 +1,9 @@
 """The one-shot all-reduce of the tensor-parallel decode step (csrc/comm_oneshot.hip: every rank stores its vector into every peer's
 receive area as 8-byte {two bf16, sequence tag} granules and sums what arrives in its own area in rank order) - protocol and arithmetic
 in ONE process: N receive areas on one GPU stand in for N peers, and the N ranks run as N slices of one launch (co-resident by
-construction: N launches on N streams may share a hardware queue and would then wait for each other until the bounded sweep expires - the
-2-rank case below also runs that way, as two concurrent launches).  No multi-GPU box has been available to the build; over xGMI the
+construction: N launches on N streams of one GPU may share a hardware queue and then wait for each other until the bounded sweep expires -
+seen on the GPU box with 4 streams, and with 2 once the process had other streams open; the production form, one rank per launch and per
+GPU, is exercised by the absent-peer test).  No multi-GPU box has been available to the build; over xGMI the
 areas are peer-mapped and nothing else changes.  Partition: SURVEY.md section 8e."""
 import pytest
 import torch
@@ -50,25 +51,6 @@ def test_one_shot_all_reduce_over_n_areas(B, N, n):
     B.allreduce_oneshot_all(areas, cap, xs, xs, seqs, err)
     torch.cuda.synchronize()
     assert all(torch.equal(x, want) for x in xs) and int(err.item()) == 0
-
-
-def test_two_ranks_as_two_concurrent_launches(B):
-    """the production launch form (one rank per launch) with two ranks on two streams of one GPU"""
-    dev, N, n, cap = "cuda:0", 2, 4096, 4096
-    areas = [B.oneshot_area(N, cap, dev) for _ in range(N)]
-    seqs = [B.oneshot_seq(dev) for _ in range(N)]
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
-    streams = [torch.cuda.Stream() for _ in range(N)]
-    for it in range(4):
-        xs = [torch.randn(n).to(torch.bfloat16).to(dev) for _ in range(N)]
-        outs = [torch.empty(n, dtype=torch.bfloat16, device=dev) for _ in range(N)]
-        torch.cuda.synchronize()
-        for r in (range(N) if it % 2 == 0 else reversed(range(N))):      # launch order must not matter
-            with torch.cuda.stream(streams[r]):
-                B.allreduce_oneshot(areas, r, cap, xs[r], outs[r], seqs[r], err, stream=streams[r].cuda_stream)
-        torch.cuda.synchronize()
-        assert int(err.item()) == 0
-        assert all(torch.equal(o, _ref(xs)) for o in outs)
 
 
 def test_absent_peer_ends_with_an_error_and_nan(B):

@@ -209,3 +209,53 @@ def test_save_projector_writes_the_reference_checkpoint(env, tmp_path):
     tr.eng.finalize()
     for n, t in before.items():
         assert torch.equal(tr.eng.w[n], t), n
+
+
+def test_long_sequence_step_against_the_reference(env):
+    """The length the reference trains up to (ref:script/pretrain.sh:44 --model_max_length 2048, with FlashAttention-2 and gradient
+    checkpointing, ref:vis_zephyr/train/train_mem.py:8-10): one sample of 5 tiles + a 900-id caption -> S = 1059 spliced rows, against
+    the reference's own loss.backward() at that length (tests/golden/stage1_long.npz, oracle/pin_train_step.py --long).  The attention
+    backward of the frozen Zephyr layers runs at S > 1024; its scratch is bounded per pass (train_engine.inc ATTN_BWD_CAP), not per batch."""
+    import os
+    from oracle import pin_train_step
+    from util import GOLDEN
+    path = os.path.join(GOLDEN, "stage1_long.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/stage1_long.npz not generated (oracle/pin_train_step.py --long)")
+    g = dict(np.load(path, allow_pickle=False))
+    from vz_hip import synth
+    from vz_hip.train import Stage1Trainer
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    cfg = env["cfg"]
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=2, num_attention_heads=cfg.n_heads,
+                         num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+                         sliding_window=cfg.sliding_window, eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=1100, max_tiles=5, max_text=912)
+    tr = Stage1Trainer(model)
+    tr.set_masters_from_reference((k, v) for k, v in env["sd"].items() if k.startswith("model.mm_projector."))
+    ids, mask, lab, images = pin_train_step.long_batch(cfg)
+    tr.zero_grad()
+    loss = tr.forward_backward(ids, mask, lab, images)
+    ref_loss = float(g["loss"])
+    record("stage1 long-sequence loss", hip=loss, reference=ref_loss, rel=abs(loss - ref_loss) / ref_loss, S=899 + 160)
+    assert abs(loss - ref_loss) <= 2e-3 * ref_loss, (loss, ref_loss)
+    grads = tr.reference_grads()
+    names = [str(n) for n in g["grad_names"]]
+    worst = 0.0
+    for n, ref_norm in zip(names, g["grad_norms"]):
+        got = float(grads[n].double().norm())
+        assert np.isfinite(got), n
+        worst = max(worst, abs(got - ref_norm) / max(ref_norm, 1e-30))
+    record("stage1 long-sequence gradient norms vs reference", worst_rel=worst, tensors=len(names))
+    assert worst <= 5e-2, worst
+    for key in [k for k in g if k.startswith("grad.") and k.endswith(".sub")]:
+        n = key[len("grad."):-len(".sub")]
+        stride = int(g[f"grad.{n}.stride"])
+        mine = grads[n].reshape(-1)[::stride][:4096]
+        mx, l2 = errs(mine.cpu(), torch.from_numpy(g[key]))
+        record(f"stage1 long-sequence gradient slice {n}", max_err=mx, l2_err=l2)
+        assert l2 <= 6e-2, (n, l2)
+    del tr, model
+    torch.cuda.empty_cache()
