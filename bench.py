@@ -485,10 +485,14 @@ def main():
         # chain, vz_tune_set(28, 0) / other devices - the 129 weight-streaming GEMV launches (weights only)
         kv_bytes = 2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * 2 * (S + n_prof // 2)
         launches_per_token = n_l / n_prof
-        bytes_per_launch = (w_bytes + kv_bytes) if persist else w_bytes / launches_per_token
+        # (default route since round 3: the O projection's weights are streamed by the attention + O launch, attn_o_fused.hip - its bytes
+        # are not the GEMV launches' then: 3 GEMVs per layer + the lm_head)
+        o_fused = abs(launches_per_token - (3 * cfg.n_layers + 1)) < 0.5
+        gemv_bytes = w_bytes - (2 * cfg.n_layers * cfg.hidden * cfg.n_heads * cfg.head_dim if o_fused else 0)
+        bytes_per_launch = (w_bytes + kv_bytes) if persist else gemv_bytes / launches_per_token
         ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "decode_token_kernel (one resident grid per token: 129 weight streams + 32 attention phases)" if persist
-                else "gemv_bf16_kernel<1> (decode weight stream)", "achieved": round(ach, 1),
+                else "gemv_bf16_kernel<1> (decode weight stream" + ("; the O projection rides in the attention launch" if o_fused else "") + ")", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(persist),
                 "launches": n_l, "launches_per_token": round(launches_per_token, 2), "avg_launch_ms": round(avg_ms, 5),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),

@@ -38,6 +38,7 @@ extern "C" {
 /* (1 was the hand-off of the one-launch batch-1 attention half, removed in round 2: it never beat the three kernels) */
 #define VZ_ASYNC_STREAMK 2    /* stream-K fix-up of the 256^2 GEMM: the tile was written as NaN, never as a sum of stale slots */
 #define VZ_ASYNC_ONESHOT 4    /* a peer's vector never arrived in the one-shot all-reduce (comm_oneshot.hip): the output was poisoned with NaN */
+#define VZ_ASYNC_ATTN_O 5     /* the O-projection workgroups of the fused attention + O launch (attn_o_fused.hip) never saw the mergers arrive: x poisoned with NaN */
 #define VZ_ASYNC_PERSIST 3    /* a phase hand-off of the persistent decode-token kernel (decode_persist.hip) expired: that token's logits are garbage */
 
 typedef void* vz_stream;

@@ -119,3 +119,33 @@ def test_expired_hand_off_ends_the_launch_and_raises(small):
         ids2, lg2, _ = _steps(model, emb, 2, persist=1)
         assert torch.equal(ids2, ids_ref) and torch.equal(lg2, lg_ref)
     assert B.VZ_ASYNC_PERSIST == 3
+
+
+@pytest.mark.parametrize("S", [5, 127, 300, 1100, 2200])
+def test_fused_attention_o_launch_equals_the_two_launches(small, S):
+    """csrc/attn_o_fused.hip (the default batch-1 route: the O projection's workgroups ride in the decode attention's grid and stream
+    their weights under its latency chain) against vz_tune_set(30, 0) (attention kernel, then the O projection's GEMV): the same
+    arithmetic in the same order - logits and ids EQUAL bit for bit, eager and through the captured graph."""
+    from vz_hip import binding as B
+    cfg, synth, model = small
+    eng = model.engine
+    emb = eng.embed_tokens(synth.synth_ids(S, cfg.vocab, image_pos=-1, seed=700 + S).unsqueeze(0))
+    res = {}
+    for fused in (1, 0):
+        B.check(B.lib().vz_tune_set(30, fused))
+        try:
+            _, last = eng.prefill(emb, [S], all_logits=False, last_logits=True)
+            eng.decode_begin(last.argmax(-1).to(torch.int32), [S], [S])
+            ids, lg = eng.decode_steps(5, return_logits=True)
+            _, last = eng.prefill(emb, [S], all_logits=False, last_logits=True)
+            eng.decode_begin(last.argmax(-1).to(torch.int32), [S], [S])
+            ids_g = eng.decode_steps(12)
+            torch.cuda.synchronize()
+            eng.check_async()
+            res[fused] = (ids[0].clone(), lg[:, 0].clone(), ids_g[0].clone())
+        finally:
+            B.check(B.lib().vz_tune_set(30, 1))
+    for fused in (1,):
+        assert torch.isfinite(res[fused][1]).all()
+        assert torch.equal(res[fused][0], res[0][0]) and torch.equal(res[fused][2], res[0][2]), fused
+        assert torch.equal(res[fused][1], res[0][1]), f"knob {fused}, S={S}: max |diff| {float((res[fused][1] - res[0][1]).abs().max()):.3e}"

@@ -254,6 +254,7 @@ struct vz_engine {
     bf16_t* d_xnorm = nullptr;   // [64, hidden]: normalised rows of a 5..16-row decode batch (the MFMA weight stream reads them from L2)
     float* d_part = nullptr;     // decode attention partials
     unsigned* d_ticket = nullptr; // arrival counters of the fused decode attention
+    unsigned* d_ao_done = nullptr; // arrival word of the attention + O-projection launch (attn_o_fused.hip); zeroed with the step counter
     int* d_ferr = nullptr;        // raised by a bounded device-side wait that expired
     int nsplit = 32;                 // upper bound: a split takes >= 128 keys, the splits beyond ceil(len / 128) leave at once
     VzTokState* tok = nullptr;          // persistent decode-token kernel (decode_persist.hip): per-layer pointer table + hand-off vectors + arrival counters
@@ -478,6 +479,8 @@ extern "C" int vz_engine_create(const vz_config* cfg, vz_engine** out) {
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_ticket, 4096);
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_xnorm, (size_t)64 * c.hidden * sizeof(bf16_t));
     if (er == hipSuccess) er = hipMemset(e->d_ticket, 0, 4096);
+    if (er == hipSuccess) er = hipMalloc((void**)&e->d_ao_done, 64);
+    if (er == hipSuccess) er = hipMemset(e->d_ao_done, 0, 64);
     if (er == hipSuccess) er = hipMalloc((void**)&e->d_ferr, sizeof(int));
     if (er == hipSuccess) er = hipMemset(e->d_ferr, 0, sizeof(int));
     if (er != hipSuccess) {
@@ -501,6 +504,7 @@ extern "C" int vz_engine_destroy(vz_engine* e) {
     if (e->d_logits) hipFree(e->d_logits);
     if (e->d_part) hipFree(e->d_part);
     if (e->d_ticket) hipFree(e->d_ticket);
+    if (e->d_ao_done) hipFree(e->d_ao_done);
     if (e->d_ferr) hipFree(e->d_ferr);
     if (e->d_xnorm) hipFree(e->d_xnorm);
     if (e->d_gather) (void)hipFree(e->d_gather);
@@ -836,6 +840,7 @@ extern "C" int vz_embed_splice(vz_engine* e, const int* d_kind, const int* d_idx
 // call sites through RCCL (all-reduce over one rank = identity, all-gather = copy), so the collective plumbing - library,
 // dtypes, in-place buffers, stream order, the vocab-parallel gather + repack - runs on a single GPU.
 static int g_force_comm = 0;
+static int g_attn_o = 1;           // vz_tune_set(30, 0): batch-1 decode attention and O projection as two launches again (attn_o_fused.hip off)
 static int g_persist_decode = 0;   // vz_tune_set(28, 1): batch-1 decode steps as one resident grid per token (decode_persist.hip) instead of the launch chain.
                                    // Off by default: measured 282 vs 339 tok/s (profiles/r03_persist_stamps.txt: the phase edges + the attention phase leave HBM idle longer than the launch boundaries they replace)
 static int g_attn_nsplit = 0;   // vz_tune_set(10, n): context splits of the fused decode attention (0 = engine default)
@@ -1195,6 +1200,8 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
         { ProfScope ps(e, K_OTHER, s); RC(vz_launch_embed_tokens(cur, B, H, WB("llm.embed", (long)c.vocab * H), x, s)); }
         for (int i = 0; i < c.n_layers; ++i) {
             const std::string p = "llm." + std::to_string(i) + ".";
+            const bool fuse_ao = g_attn_o && B == 1 && e->tp == 1 && tp_local(e) && !c.weight_fp8 && H == 4096 && A == 4096 && Hq == 32 && Hkv == 8 &&
+                                 D == 128 && e->dec_nsplit <= 32 && e->d_ao_done;
             RC(linear(e, 1, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps,
                       W8(p + "qkv.w8", (long)QKV * H), WS(p + "qkv.ws", QKV)));
             {
@@ -1204,10 +1211,19 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
                 a.cosT = e->cosT; a.sinT = e->sinT; a.pos = pos; a.slot = slot;
                 a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_ctx = c.max_ctx; a.nsplit = e->dec_nsplit; a.window = c.sliding_window;
                 a.scale = 0.08838834764831845f;
-                RC(vz_launch_attn_decode_fused(a, s));
+                if (fuse_ao) {
+                    // batch 1 (round 3): the O projection's workgroups ride in the attention's grid and stream their weights under its latency
+                    // chain (attn_o_fused.hip); same arithmetic as the two launches, bit for bit
+                    const bf16_t* ow = WB(p + "o.w", (long)H * A);
+                    if (rc) return rc;
+                    RC(vz_launch_attn_o_fused(a, ow, att, x, e->d_ao_done, step, i, c.n_layers, e->d_ferr, s));
+                } else {
+                    RC(vz_launch_attn_decode_fused(a, s));
+                }
             }
-            RC(linear(e, 1, att, A, WB(p + "o.w", (long)H * A), A, x, H, B, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
-                      W8(p + "o.w8", (long)H * A), WS(p + "o.ws", H)));
+            if (!fuse_ao)
+                RC(linear(e, 1, att, A, WB(p + "o.w", (long)H * A), A, x, H, B, H, A, nullptr, lead ? x : nullptr, H, VZ_ACT_NONE, 0, s, nullptr, 0.f,
+                          W8(p + "o.w8", (long)H * A), WS(p + "o.ws", H)));
             RC(tp_allreduce_bf16(e, x, (size_t)B * H, s, true));
             RC(linear(e, 1, x, H, WB(p + "gu.w", 2L * I * H), H, act, I, B, 2 * I, H, nullptr, nullptr, 0, VZ_ACT_SWIGLU, 0, s, WF(p + "post_norm", H), c.rms_eps,
                       W8(p + "gu.w8", 2L * I * H), WS(p + "gu.ws", 2L * I)));
@@ -1293,6 +1309,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     if (!tp_local(e)) RC(ensure_gather(e, B, s));
     int* step = e->d_state + 4 * c.max_batch;
     VZ_CHECK_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
+    VZ_CHECK_HIP(hipMemsetAsync(e->d_ao_done, 0, sizeof(unsigned), s));      // the attention + O launch's arrival word restarts with the step counter
     // vz_tune_set(28, 1) - batch 1, one GPU, bf16 weights, Zephyr-7B geometry on a 256-CU device: the steps run as ONE resident grid
     // per token (decode_persist.hip) instead of the launch chain.  Its pointer table is (re)built here, never inside a capture.
     e->use_tok = false;
@@ -1352,7 +1369,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
     long samp_key[6] = {e->samp_on, e->samp_top_k, 0, 0, (long)(uintptr_t)e->ring, e->ring_n};
     memcpy(&samp_key[2], &e->samp_temp, 4); memcpy(&samp_key[3], &e->samp_top_p, 4);
     if (!e->dec_graph || e->dec_graph_B != B || e->dec_graph_n != n || e->dec_graph_out != d_out_ids || e->dec_graph_arena != e->arena ||
-        e->dec_graph_nsplit != e->dec_nsplit || e->dec_graph_tok != (int)e->use_tok || memcmp(e->dec_graph_samp, samp_key, sizeof(samp_key)) != 0) {
+        e->dec_graph_nsplit != e->dec_nsplit || e->dec_graph_tok != ((int)e->use_tok | (g_attn_o << 1)) || memcmp(e->dec_graph_samp, samp_key, sizeof(samp_key)) != 0) {
         if (e->dec_graph) { hipGraphExecDestroy(e->dec_graph); e->dec_graph = nullptr; }
         hipGraph_t graph;
         if (!e->cap_stream) VZ_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
@@ -1375,7 +1392,7 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
             for (int i = 0; i < n; ++i) RC(decode_step_launch(e, d_out_ids, n, nullptr, s));
             return VZ_OK;
         }
-        e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena; e->dec_graph_nsplit = e->dec_nsplit; e->dec_graph_tok = (int)e->use_tok; memcpy(e->dec_graph_samp, samp_key, sizeof(samp_key));
+        e->dec_graph_B = B; e->dec_graph_n = n; e->dec_graph_out = d_out_ids; e->dec_graph_arena = e->arena; e->dec_graph_nsplit = e->dec_nsplit; e->dec_graph_tok = (int)e->use_tok | (g_attn_o << 1); memcpy(e->dec_graph_samp, samp_key, sizeof(samp_key));
     }
     for (int i = 0; i < n; ++i) VZ_CHECK_HIP(hipGraphLaunch(e->dec_graph, s));
     return VZ_OK;
@@ -1437,6 +1454,7 @@ extern "C" int vz_test_corrupt_streamk(vz_stream stream, int tile, int arrive, i
     return vz_gemm256_corrupt_tickets((hipStream_t)stream, tile, arrive, ready);
 }
 
+extern int g_attn_o_delay;
 extern int g_gemm256_streamk, g_gemm256_skew, g_gemm256_stamps, g_gemm256_drain, g_attn_stamp_on, g_fp8_gemm_choice;
 int vz_gemm256_read_stamps(long long* host, int max_wgs, int* n_wgs);
 extern "C" int vz_tune_set(int knob, int value) {
@@ -1460,6 +1478,8 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 27) { g_wide_fp8_splits = value; return VZ_OK; }
     if (knob == 28) { g_persist_decode = value; return VZ_OK; }
     if (knob == 29) { g_oneshot = value; return VZ_OK; }
+    if (knob == 30) { g_attn_o = value; return VZ_OK; }
+    if (knob == 31) { g_attn_o_delay = value; return VZ_OK; }
     if (knob == 26) { vz_set_splitk_mid(value); return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }

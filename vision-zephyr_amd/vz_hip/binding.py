@@ -19,6 +19,7 @@ VZ_OK, VZ_ERR_ARG, VZ_ERR_HIP, VZ_ERR_STATE, VZ_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 VZ_ASYNC_STREAMK = 2
 VZ_ASYNC_PERSIST = 3
 VZ_ASYNC_ONESHOT = 4
+VZ_ASYNC_ATTN_O = 5
 ABI_VERSION = 10
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
 K_GEMM, K_GEMV, K_ATTN, K_ATTN_DEC, K_NORM, K_OTHER, K_FUSED, K_COMM = range(8)
