@@ -149,6 +149,13 @@ int vz_op_attention_split(const void* d_q, const void* d_k, const void* d_v, voi
                           float scale, int causal, int q_pos0, int window, const int* d_kv_len,
                           float* d_workspace, long workspace_floats, vz_stream stream);
 
+/* Attention BACKWARD, tile-resident (attn_bwd_flash.hip): dQ, dK, dV of softmax(scale Q K^T + mask) V without an Sq x Sk tensor in memory - the
+ * form the reference trains through (ref:vis_zephyr/train/zephyr_flash_attn_monkey_patch.py:100-124; masks as vz_op_attention: causal,
+ * sliding window, per-sample key count).  head_dim 128.  q, dO, dq [B,Sq,Hq,D] bf16; k, v [B,Hkv,Sk,D] bf16; dk, dv [B,Hkv,Sk,D] fp32
+ * (dkv_fp32 = 1) or bf16, already summed over the query heads of a KV head.  d_ws: >= 2 * B * Hq * Sq + 64 floats. */
+int vz_op_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const void* d_dO, void* d_dq, void* d_dk, void* d_dv, int dkv_fp32,
+                        int B, int Sq, int Sk, int Hq, int Hkv, int head_dim, float scale, int causal, int window, const int* d_kv_len,
+                        float* d_ws, long ws_floats, vz_stream stream);
 /* RoPE (rotate-half, hf:models/mistral/modeling_mistral.py:51-81) on the Q and K heads of a fused QKV row
  * [B*S, (Hq+2Hkv)*D] + append of K/V to the cache [B][Hkv][max_ctx][D].  d_pos / d_slot: int32 [B*S] position
  * id and cache slot of every token (slot < 0: token not cached).  d_q_out bf16 [B*S,Hq,D].  D = 128. */

@@ -23,6 +23,10 @@ import torch  # noqa: E402
 from vz_hip import synth  # noqa: E402
 from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM  # noqa: E402
 
+from vz_hip import binding as _B  # noqa: E402
+for kv in filter(None, os.environ.get("VZ_TUNE", "").split(",")):       # experiments: "knob=value,..." for vz_tune_set (32=0: materialising attention backward)
+    _k, _v = (int(t) for t in kv.split("="))
+    _B.check(_B.lib().vz_tune_set(_k, _v))
 nums = [int(a) for a in sys.argv[1:] if a.isdigit()]
 Bn = nums[0] if nums else 64
 layers = nums[1] if len(nums) > 1 else 32
@@ -77,7 +81,7 @@ if TRAIN:
     for it in range(4):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        losses.append(tr.step(ids, mask, labels, tiles, lr=2e-3, micro_batch=MB)      # --mm_projector_lr (ref:script/pretrain.sh:16))
+        losses.append(tr.step(ids, mask, labels, tiles, lr=2e-3, micro_batch=MB))      # --mm_projector_lr (ref:script/pretrain.sh:16)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     best = min(times[1:])

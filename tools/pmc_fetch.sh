@@ -30,8 +30,9 @@ P
 }
 mkdir -p $R/gpurun_out
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pm1; VZ_NO_GRAPH=1 VZ_REPS=1 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "gemv_bf16_kernel|attn_decode_fused" -d /tmp/pm1 -o p --output-format csv -- python3 $R/tools/bench_decode.py "" > /tmp/pm1.log 2>&1
-  echo "== decode launch chain $C"; summ /tmp/pm1 $R/gpurun_out/pmc_decode_chain_$C.json "decode launch chain (GEMV + decode attention), configs[2], $C"
+  rm -rf /tmp/pm1; VZ_NO_GRAPH=1 VZ_REPS=1 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "gemv_bf16_kernel|attn_decode_fused|attn_o_fused" -d /tmp/pm1 -o p --output-format csv -- python3 $R/tools/bench_decode.py "" > /tmp/pm1.log 2>&1
+  echo "== decode launch chain $C"; summ /tmp/pm1 $R/gpurun_out/pmc_decode_chain_$C.json "decode launch chain (GEMV + attention|O launch), configs[2], $C"
+  [ "$PMC_ONLY" = chain ] && continue
   rm -rf /tmp/pm2; VZ_NO_GRAPH=1 VZ_REPS=1 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "decode_token_kernel" -d /tmp/pm2 -o p --output-format csv -- python3 $R/tools/bench_decode.py "28=1" > /tmp/pm2.log 2>&1
   echo "== persistent decode-token kernel $C"; summ /tmp/pm2 $R/gpurun_out/pmc_decode_token_$C.json "persistent decode-token kernel, configs[2], $C"
   rm -rf /tmp/pm3; rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "gemm" -d /tmp/pm3 -o p --output-format csv -- python3 $R/tools/pmc_gemm.py > /tmp/pm3.log 2>&1

@@ -177,6 +177,20 @@ extern "C" int vz_op_attention_split(const void* q, const void* k, const void* v
     a.part = ws; a.part_floats = (size_t)ws_floats;
     return vz_launch_attention(a, (hipStream_t)s);
 }
+extern "C" int vz_op_attention_bwd(const void* q, const void* k, const void* v, const void* dO, void* dq, void* dk, void* dv, int dkv_fp32, int B,
+                                   int Sq, int Sk, int Hq, int Hkv, int head_dim, float scale, int causal, int window, const int* kv_len,
+                                   float* ws, long ws_floats, vz_stream s) {
+    VZ_CHECK_ARG(B > 0 && Sq > 0 && Sk > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention_bwd: bad shape");
+    VZ_CHECK_ARG(head_dim == 128, "attention_bwd: the tile-resident backward is built for head_dim 128 (the Zephyr layers), got %d", head_dim);
+    FlashBwdArgs f;
+    f.q = (const bf16_t*)q; f.k = (const bf16_t*)k; f.v = (const bf16_t*)v; f.dO = (const bf16_t*)dO; f.B = B; f.Sq = Sq; f.Sk = Sk; f.Hq = Hq; f.Hkv = Hkv; f.D = head_dim;
+    const long A = (long)Hq * head_dim;
+    f.q_bs = f.o_bs = f.dq_bs = (long)Sq * A; f.q_ss = f.o_ss = f.dq_ss = A; f.q_hs = f.o_hs = f.dq_hs = head_dim;
+    f.k_bs = f.v_bs = f.dk_bs = (long)Hkv * Sk * head_dim; f.k_ss = f.v_ss = f.dk_ss = head_dim; f.k_hs = f.v_hs = f.dk_hs = (long)Sk * head_dim;
+    f.scale = scale; f.causal = causal; f.window = window; f.kv_len = kv_len;
+    f.dq = (bf16_t*)dq; f.dk = dk; f.dv = dv; f.dkv_fp32 = dkv_fp32;
+    return vz_launch_flash_bwd(f, ws, ws_floats > 0 ? (size_t)ws_floats * 4 : 0, (hipStream_t)s);
+}
 extern "C" int vz_op_rope_kv(const void* qkv, int ld, void* q_out, void* kc, void* vc, const float* cosT, const float* sinT,
                              const int* pos, const int* slot, int B, int S, int Hq, int Hkv, int D, int max_ctx, vz_stream s) {
     VZ_CHECK_ARG(qkv && q_out && kc && vc && cosT && sinT && pos && slot && B > 0 && S > 0, "rope: bad argument");
@@ -840,6 +854,7 @@ extern "C" int vz_embed_splice(vz_engine* e, const int* d_kind, const int* d_idx
 // call sites through RCCL (all-reduce over one rank = identity, all-gather = copy), so the collective plumbing - library,
 // dtypes, in-place buffers, stream order, the vocab-parallel gather + repack - runs on a single GPU.
 static int g_force_comm = 0;
+static int g_flash_bwd = 1;               // vz_tune_set(32, 0): the training step's head-128 attention backward through the materialising batched-GEMM route again (A/B; train_engine.inc)
 static int g_attn_o = 1;           // vz_tune_set(30, 0): batch-1 decode attention and O projection as two launches again (attn_o_fused.hip off)
 static int g_persist_decode = 0;   // vz_tune_set(28, 1): batch-1 decode steps as one resident grid per token (decode_persist.hip) instead of the launch chain.
                                    // Off by default: measured 282 vs 339 tok/s (profiles/r03_persist_stamps.txt: the phase edges + the attention phase leave HBM idle longer than the launch boundaries they replace)
@@ -1480,6 +1495,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 29) { g_oneshot = value; return VZ_OK; }
     if (knob == 30) { g_attn_o = value; return VZ_OK; }
     if (knob == 31) { g_attn_o_delay = value; return VZ_OK; }
+    if (knob == 32) { g_flash_bwd = value; return VZ_OK; }
     if (knob == 26) { vz_set_splitk_mid(value); return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }

@@ -269,6 +269,20 @@ int vz_launch_allreduce_oneshot(void* const* areas, int rank, int n_ranks, int m
 int vz_launch_allreduce_oneshot_all(void* const* areas, int n_ranks, int max_elems, const bf16_t* const* in, bf16_t* const* out, int n,
                                     unsigned* const* seq, int* err, hipStream_t s);
 
+// attn_bwd_flash.hip: tile-resident attention backward (head_dim 128; causal / window / padding masks; grouped KV heads).  dq bf16 strided
+// like q; dk / dv [Sk, D] blocks per (batch, KV head), fp32 or bf16, same strides for both.  scratch: vz_flash_bwd_scratch_bytes.
+struct FlashBwdArgs {
+    const bf16_t *q, *k, *v, *dO;
+    int B, Sq, Sk, Hq, Hkv, D;
+    long q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ss, o_hs;
+    float scale; int causal, window; const int* kv_len;
+    bf16_t* dq; long dq_bs, dq_ss, dq_hs;
+    void *dk, *dv; int dkv_fp32; long dk_bs, dk_ss, dk_hs;
+};
+size_t vz_flash_bwd_scratch_bytes(int B, int Sq, int Hq);
+bool vz_flash_bwd_ok(const FlashBwdArgs& a);
+int vz_launch_flash_bwd(const FlashBwdArgs& a, void* scratch, size_t scratch_bytes, hipStream_t s);
+
 // decode attention with RoPE + KV append + split combine fused into one launch (attn_decode.hip)
 struct AttnDecodeFusedArgs {
     const bf16_t* qkv;     // [B, (Hq+2Hkv)*D]

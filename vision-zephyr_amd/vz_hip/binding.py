@@ -60,6 +60,7 @@ SYMBOLS = {
     "vz_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _P]),
     "vz_op_rmsnorm": (_I, [_P, _I, _P, _I, _P, _I, _I, _F, _P]),
     "vz_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I] + [_L] * 12 + [_F, _I, _I, _I, _P, _P]),
+    "vz_op_attention_bwd": (_I, [_P] * 7 + [_I] * 7 + [_F, _I, _I, _P, _P, _L, _P]),
     "vz_op_attention_split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I] + [_L] * 12 + [_F, _I, _I, _I, _P, _P, _L, _P]),
     "vz_op_argmax": (_I, [_P, _I, _I, _P, _P]),
     "vz_op_rope_kv": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -370,6 +371,26 @@ def rmsnorm(x, w, eps):
     check(lib().vz_op_rmsnorm(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(w), x.shape[0], x.shape[1], eps,
                               stream_ptr(x.device)))
     return y
+
+
+def attention_bwd(q, k, v, dO, scale, causal=False, window=0, kv_len=None, dkv_fp32=True):
+    """Tile-resident attention backward (vz_op_attention_bwd, head_dim 128): q, dO [B,Sq,Hq,D], k / v [B,Hkv,Sk,D], all contiguous bf16
+    -> dq [B,Sq,Hq,D] bf16, dk, dv [B,Hkv,Sk,D] fp32 (or bf16), summed over the query heads of a KV head."""
+    _need_cuda(q, k, v, dO, kv_len)
+    B, Sq, Hq, D = q.shape
+    Hkv, Sk = k.shape[1], k.shape[2]
+    for t in (q, k, v, dO):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    assert dO.shape == q.shape and v.shape == k.shape
+    if kv_len is not None:
+        assert kv_len.dtype == torch.int32
+    dq = torch.empty_like(q)
+    dk = torch.empty(B, Hkv, Sk, D, dtype=torch.float32 if dkv_fp32 else torch.bfloat16, device=q.device)
+    dv = torch.empty_like(dk)
+    ws = torch.empty(2 * B * Hq * Sq + 64, dtype=torch.float32, device=q.device)
+    check(lib().vz_op_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(dO), ptr(dq), ptr(dk), ptr(dv), int(dkv_fp32), B, Sq, Sk, Hq, Hkv, D,
+                                    float(scale), int(causal), int(window), ptr(kv_len), ptr(ws), ws.numel(), stream_ptr(q.device)))
+    return dq, dk, dv
 
 
 def attention(q, k, v, scale, causal=False, q_pos0=0, window=0, kv_len=None, workspace=None):
