@@ -156,6 +156,12 @@ int vz_op_attention_split(const void* d_q, const void* d_k, const void* d_v, voi
 int vz_op_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const void* d_dO, void* d_dq, void* d_dk, void* d_dv, int dkv_fp32,
                         int B, int Sq, int Sk, int Hq, int Hkv, int head_dim, float scale, int causal, int window, const int* d_kv_len,
                         float* d_ws, long ws_floats, vz_stream stream);
+/* Two helpers of the training step (train.hip) at op level: vz_op_transpose dst[c][r] = src[r][c] (bf16 [R,C] -> [C,R]; 64 x 64 tiles through the
+ * hardware transposing LDS read when R, C and the leading dimensions are multiples of 8 and the bases 16-byte aligned), vz_op_colsum
+ * d_out[c] += sum_r y[r][c] (fp32, the bias gradients; fixed summation order) with d_part >= vz_op_colsum_groups(rows) * cols floats. */
+int vz_op_transpose(const void* d_src, long src_ld, void* d_dst, long dst_ld, int R, int C, vz_stream stream);
+int vz_op_colsum(const void* d_y, int ld, long rows, int cols, float* d_part, long part_floats, float* d_out, vz_stream stream);
+int vz_op_colsum_groups(long rows);
 /* RoPE (rotate-half, hf:models/mistral/modeling_mistral.py:51-81) on the Q and K heads of a fused QKV row
  * [B*S, (Hq+2Hkv)*D] + append of K/V to the cache [B][Hkv][max_ctx][D].  d_pos / d_slot: int32 [B*S] position
  * id and cache slot of every token (slot < 0: token not cached).  d_q_out bf16 [B*S,Hq,D].  D = 128. */

@@ -42,7 +42,7 @@ hf.mm_patch_merge_type = "flat"
 hf.image_aspect_ratio = "anyres"
 hf.mm_grid_pinpoints = "[[336, 672], [672, 336], [336, 1008], [1008, 336], [672, 672]]"
 hf.mm_hidden_size = 5120
-MAXB = min(Bn, 16)
+MAXB = min(Bn, max(16, MB)) if TRAIN else min(Bn, 16)
 model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, device="cuda:0", max_batch=MAXB, max_ctx=S + 8, max_tiles=N_TILES * MAXB,
                                             max_text=N_IDS + 8)
 dev = model.device
@@ -89,6 +89,8 @@ if TRAIN:
     print(f"  losses over 4 steps on the same batch: {' '.join(f'{v:.4f}' for v in losses)}")
     print(f"  step time: {best * 1e3:8.1f} ms  ({Bn / best:6.1f} samples/s, {f_step / best / 1e12:6.1f} TFLOP/s algorithmic = {f_step / best / 2.5e15 * 100:4.1f} % of 2.5 PF; "
           f"first step incl. allocations {times[0] * 1e3:.0f} ms)")
+    free, total = torch.cuda.mem_get_info()
+    print(f"  device memory in use after the steps: {(total - free) / 2**30:.1f} GiB of {total / 2**30:.0f}")
     sys.exit(0)
 run()
 enc, llm = min((run() for _ in range(3)), key=sum)

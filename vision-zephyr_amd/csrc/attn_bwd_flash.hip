@@ -44,20 +44,25 @@ __device__ __forceinline__ bf16x4 tr16(const char* p) {
     return __builtin_bit_cast(bf16x4, v);
 }
 
-// rows [row0, row0 + 64) (clamped to last_row) x 128 of a strided bf16 matrix -> LDS tile, 4 x 16 bytes per thread
-__device__ __forceinline__ void stage_tile(const bf16_t* base, long row_stride, int row0, int last_row, char* dst, int tid) {
-    uint4 v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = i * 256 + tid, r = ch >> 4, c16 = ch & 15;
-        const int row = min(row0 + r, last_row);
-        v[i] = *(const uint4*)(base + (size_t)row * row_stride + c16 * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = i * 256 + tid, r = ch >> 4, c16 = ch & 15;
-        *(uint4*)(dst + r * FB_TS + c16 * 16) = v[i];
-    }
+// rows [row0, row0 + 64) (clamped to last_row) x 128 of a strided bf16 matrix -> registers (4 x 16 bytes per thread) -> LDS tile: the loads of
+// tile t + 1 are issued before the products of tile t and land under them
+struct Tile4 { uint4 a, b, c, d; };          // (named members, passed by value: an array handed around by reference ends up in scratch)
+__device__ __forceinline__ uint4 tile_load1(const bf16_t* base, long row_stride, int row0, int last_row, int i, int tid) {
+    const int ch = i * 256 + tid, r = ch >> 4, c16 = ch & 15;
+    return *(const uint4*)(base + (size_t)min(row0 + r, last_row) * row_stride + c16 * 8);
+}
+__device__ __forceinline__ Tile4 tile_load(const bf16_t* base, long row_stride, int row0, int last_row, int tid) {
+    Tile4 t;
+    t.a = tile_load1(base, row_stride, row0, last_row, 0, tid); t.b = tile_load1(base, row_stride, row0, last_row, 1, tid);
+    t.c = tile_load1(base, row_stride, row0, last_row, 2, tid); t.d = tile_load1(base, row_stride, row0, last_row, 3, tid);
+    return t;
+}
+__device__ __forceinline__ void tile_store(const Tile4 t, char* dst, int tid) {
+    const int r = tid >> 4, c16 = tid & 15;          // chunk i * 256 + tid: row i * 16 + r
+    *(uint4*)(dst + (r) * FB_TS + c16 * 16) = t.a;
+    *(uint4*)(dst + (16 + r) * FB_TS + c16 * 16) = t.b;
+    *(uint4*)(dst + (32 + r) * FB_TS + c16 * 16) = t.c;
+    *(uint4*)(dst + (48 + r) * FB_TS + c16 * 16) = t.d;
 }
 
 // Z[nt][r] = sum_d T[nt * 16 + 4 g + r][d] * R[c][d]   (T = the LDS tile, R = the lane's resident row fragments)
@@ -127,11 +132,18 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(FlashBwdParams p) 
 
     // ---- pass 1: the row statistics ----
     float m_run = -INFINITY, l_run = 0.f, t_run = 0.f;
+    Tile4 ka = tile_load(kb, p.k_ss, t_begin * FB_T, last_key, tid);       // (unconditional: rows are clamped)
+    Tile4 va = tile_load(vb, p.v_ss, t_begin * FB_T, last_key, tid);
     for (int t = t_begin; t < t_end; ++t) {
         __syncthreads();
-        stage_tile(kb, p.k_ss, t * FB_T, last_key, Ks, tid);
-        stage_tile(vb, p.v_ss, t * FB_T, last_key, Vs, tid);
+        tile_store(ka, Ks, tid);
+        tile_store(va, Vs, tid);
         __syncthreads();
+        {   // the next tile (after the last one of pass 1: the first one of pass 2)
+            const int tn = t + 1 < t_end ? t + 1 : t_begin;
+            ka = tile_load(kb, p.k_ss, tn * FB_T, last_key, tid);
+            va = tile_load(vb, p.v_ss, tn * FB_T, last_key, tid);
+        }
         f32x4 s[4], dp[4];
         tile_product(Ks, qf, s, c, g);
         tile_product(Vs, dof, dp, c, g);
@@ -176,9 +188,14 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(FlashBwdParams p) 
     for (int dt = 0; dt < 8; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int t = t_begin; t < t_end; ++t) {
         __syncthreads();
-        stage_tile(kb, p.k_ss, t * FB_T, last_key, Ks, tid);
-        stage_tile(vb, p.v_ss, t * FB_T, last_key, Vs, tid);
+        tile_store(ka, Ks, tid);
+        tile_store(va, Vs, tid);
         __syncthreads();
+        {
+            const int tn = min(t + 1, t_end - 1);       // (the last iteration re-requests its own tile: no branch around the arrays)
+            ka = tile_load(kb, p.k_ss, tn * FB_T, last_key, tid);
+            va = tile_load(vb, p.v_ss, tn * FB_T, last_key, tid);
+        }
         f32x4 s[4], dp[4];
         tile_product(Ks, qf, s, c, g);
         tile_product(Vs, dof, dp, c, g);
@@ -240,21 +257,31 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(FlashBwdParams p)
     f32x4 dv[8], dk[8];
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) { dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    for (int j = 0; j < grp; ++j) {
-        const int h = hk * grp + j;
-        const bf16_t* qb = p.q + (size_t)b * p.q_bs + (size_t)h * p.q_hs;
-        const bf16_t* ob = p.dO + (size_t)b * p.o_bs + (size_t)h * p.o_hs;
-        const size_t so = ((size_t)b * p.Hq + h) * p.Sq;
-        for (int t = t_begin; t < t_end; ++t) {
+    const int n_t = max(t_end - t_begin, 0), n_it = grp * n_t, n_t1 = max(n_t, 1);
+    const bf16_t* q_b = p.q + (size_t)b * p.q_bs + (size_t)(hk * grp) * p.q_hs;
+    const bf16_t* o_b = p.dO + (size_t)b * p.o_bs + (size_t)(hk * grp) * p.o_hs;
+#define Q_BASE(it) (q_b + (size_t)((it) / n_t1) * p.q_hs)
+#define O_BASE(it) (o_b + (size_t)((it) / n_t1) * p.o_hs)
+    Tile4 qa = tile_load(Q_BASE(0), p.q_ss, t_begin * FB_T, last_q, tid);
+    Tile4 oa = tile_load(O_BASE(0), p.o_ss, t_begin * FB_T, last_q, tid);
+    for (int it = 0; it < n_it; ++it) {          // (query head of the group, query tile)
+        {
+            const int h = hk * grp + it / n_t1, t = t_begin + it % n_t1;
+            const size_t so = ((size_t)b * p.Hq + h) * p.Sq;
             __syncthreads();
-            stage_tile(qb, p.q_ss, t * FB_T, last_q, Qs, tid);
-            stage_tile(ob, p.o_ss, t * FB_T, last_q, Os, tid);
+            tile_store(qa, Qs, tid);
+            tile_store(oa, Os, tid);
             if (tid < FB_T) {
                 const int i = t * FB_T + tid;
                 lse_s[tid] = i < p.Sq ? p.lse[so + i] : INFINITY;        // a row past the end: P = exp2(-inf) = 0
                 del_s[tid] = i < p.Sq ? p.delta[so + i] : 0.f;
             }
             __syncthreads();
+            {
+                const int in = min(it + 1, n_it - 1), tn = t_begin + in % n_t1;
+                qa = tile_load(Q_BASE(in), p.q_ss, tn * FB_T, last_q, tid);
+                oa = tile_load(O_BASE(in), p.o_ss, tn * FB_T, last_q, tid);
+            }
             f32x4 s[4], dp[4];
             tile_product(Qs, kf, s, c, g);
             tile_product(Os, vf, dp, c, g);
@@ -280,6 +307,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(FlashBwdParams p)
             tile_accumulate(Qs, dsf, dk, c, g);
         }
     }
+#undef Q_BASE
+#undef O_BASE
     if (k_valid) {
         const size_t o = (size_t)b * p.dk_bs + (size_t)hk * p.dk_hs + (size_t)key * p.dk_ss;
 #pragma unroll

@@ -177,6 +177,15 @@ extern "C" int vz_op_attention_split(const void* q, const void* k, const void* v
     a.part = ws; a.part_floats = (size_t)ws_floats;
     return vz_launch_attention(a, (hipStream_t)s);
 }
+// two helpers of the training step at op level (parity tests): dst[c][r] = src[r][c], and out[c] += sum_r y[r][c] through `part`
+extern "C" int vz_op_transpose(const void* src, long src_ld, void* dst, long dst_ld, int R, int C, vz_stream s) {
+    return vz_launch_transpose((const bf16_t*)src, src_ld, 0, 0, (bf16_t*)dst, dst_ld, 0, 0, R, C, 1, 1, 0, (hipStream_t)s);
+}
+extern "C" int vz_op_colsum(const void* y, int ld, long rows, int cols, float* part, long part_floats, float* out, vz_stream s) {
+    VZ_CHECK_ARG(part_floats >= (long)vz_colsum_groups(rows) * cols, "colsum: scratch of %ld floats, need %ld", part_floats, (long)vz_colsum_groups(rows) * cols);
+    return vz_launch_colsum((const bf16_t*)y, ld, rows, cols, part, out, (hipStream_t)s);
+}
+extern "C" int vz_op_colsum_groups(long rows) { return vz_colsum_groups(rows); }
 extern "C" int vz_op_attention_bwd(const void* q, const void* k, const void* v, const void* dO, void* dq, void* dk, void* dv, int dkv_fp32, int B,
                                    int Sq, int Sk, int Hq, int Hkv, int head_dim, float scale, int causal, int window, const int* kv_len,
                                    float* ws, long ws_floats, vz_stream s) {

@@ -54,35 +54,47 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
 }
 
 // The same transposition in 64 x 64 tiles with 16-byte global accesses on both sides (the 32 x 32 form above moves 2 bytes per lane:
-// 8.5 % of the Stage-1 step).  A thread loads two 8-element row pieces, scatters them TRANSPOSED into LDS (tileT[c][r], pitch 72 elements
-// = 144 bytes so that a transposed row's 8-element pieces stay 16-byte aligned) and stores two 8-element pieces of output rows.
+// 8.5 % of the Stage-1 step).  A thread loads two 8-element row pieces and stores them AS THEY ARE into a row-major LDS tile (16-byte
+// stores, pitch 144 bytes); the transposition is the hardware's: ds_read_b64_tr_b16 hands lane c of a 16-lane group column c of a 4-row x
+// 16-column block, two of them are 8 consecutive source rows of one column = one 16-byte piece of an output row.  (Round 2 scattered the
+// loaded pieces transposed into LDS with sixteen 2-byte stores per thread, four lanes to a bank: 1.8 TB/s; this form: see DESIGN section 4.)
 // Needs R, C, col0 and every stride a multiple of 8 elements and 16-byte-aligned bases (the launcher checks; else the 32 x 32 kernel).
+template <int T>       // T x T tiles (64 or 128): a tile row is T * 2 contiguous bytes on both sides - 256-byte segments at T = 128
 __global__ __launch_bounds__(256) void transpose64_kernel(const bf16_t* __restrict__ src, long src_rs, long src_so, long src_si,
                                                           bf16_t* __restrict__ dst, long dst_rs, long dst_so, long dst_si, int R, int C,
                                                           int n_inner, int col0) {
-    __shared__ __attribute__((aligned(16))) bf16_t tileT[64][72];
+    constexpr int PITCH = T * 2 + 16, PPR = T / 8, NP = T * PPR / 256;       // pieces per tile row, 16-byte pieces per thread
+    __shared__ __attribute__((aligned(16))) char tile[T * PITCH];
     const int batch = blockIdx.z, o = batch / n_inner, i = batch - o * n_inner;
     const bf16_t* s = src + o * src_so + i * src_si;
     bf16_t* d = dst + o * dst_so + i * dst_si;
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    u16x8 v[2];
+    const int r0 = blockIdx.y * T, c0 = blockIdx.x * T;
+    u16x8 v[NP];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int q = threadIdx.x + k * 256, r = r0 + (q >> 3), c = c0 + (q & 7) * 8;
+    for (int k = 0; k < NP; ++k) {
+        const int q = threadIdx.x + k * 256, r = r0 + q / PPR, c = c0 + (q % PPR) * 8;
         v[k] = (r < R && c < C) ? *(const u16x8*)(s + (size_t)r * src_rs + c) : (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int q = threadIdx.x + k * 256, rl = q >> 3, cl = (q & 7) * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tileT[cl + j][rl] = v[k][j];
+    for (int k = 0; k < NP; ++k) {
+        const int q = threadIdx.x + k * 256;
+        *(u16x8*)(tile + (q / PPR) * PITCH + (q % PPR) * 16) = v[k];
     }
     __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, cc = lane & 15;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int q = threadIdx.x + k * 256, cl = q >> 3, rl = (q & 7) * 8;
-        const int c = c0 + cl, r = r0 + rl;
-        if (c < C && r < R) *(u16x8*)(d + (size_t)c * dst_rs + col0 + r) = *(const u16x8*)&tileT[cl][rl];
+    for (int k = 0; k < NP; ++k) {
+        // (column block of 16, piece of 8 source rows) of this 16-lane group: the four groups of an instruction take four neighbouring pieces
+        const int combo = (wave * NP + k) * 4 + g, cb = combo / PPR, r8 = combo % PPR;
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        const char* tp = tile + (r8 * 8 + (cc >> 2)) * PITCH + (cb * 16 + (cc & 3) * 4) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)tp);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tp + 4 * PITCH));
+        const int c = c0 + cb * 16 + cc, r = r0 + r8 * 8;
+        if (c < C && r < R) {
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            *(s16x8*)(d + (size_t)c * dst_rs + col0 + r) = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
     }
 }
 
@@ -415,6 +427,31 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const bf16_t* __restri
     for (long r = blockIdx.y; r < rows; r += gridDim.y) s += bf16_to_f32(y[r * ld + c]);
     part[(size_t)blockIdx.y * cols + c] = s;
 }
+// the same sums with 16-byte accesses (cols % 8 == 0, ld % 8 == 0, y 16-byte aligned): 8 columns per thread, four rows in flight
+__global__ __launch_bounds__(256) void colsum_part8_kernel(const bf16_t* __restrict__ y, int ld, long rows, int cols, float* __restrict__ part) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c >= cols) return;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long G = gridDim.y;
+    long r = blockIdx.y;
+    for (; r + 3 * G < rows; r += 4 * G) {
+        u16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const u16x8*)(y + (r + u * G) * ld + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += bf16_to_f32(v[u][j]);
+    }
+    for (; r < rows; r += G) {
+        const u16x8 v = *(const u16x8*)(y + r * ld + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += bf16_to_f32(v[j]);
+    }
+    float* o = part + (size_t)blockIdx.y * cols + c;
+    *(f32x4*)o = (f32x4){s[0], s[1], s[2], s[3]};
+    *(f32x4*)(o + 4) = (f32x4){s[4], s[5], s[6], s[7]};
+}
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int G, int cols, float* __restrict__ out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
@@ -500,8 +537,11 @@ int vz_launch_transpose(const bf16_t* src, long src_rs, long src_so, long src_si
     const long strides[] = {src_rs, src_so, src_si, dst_rs, dst_so, dst_si, (long)R, (long)C, (long)col0};
     bool wide = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
     for (long v : strides) wide = wide && (v & 7) == 0;
-    if (wide)
-        hipLaunchKernelGGL(transpose64_kernel, dim3((C + 63) / 64, (R + 63) / 64, n_outer * n_inner), dim3(256), 0, s, src, src_rs, src_so, src_si, dst,
+    if (wide && R >= 1024 && C >= 1024)
+        hipLaunchKernelGGL((transpose64_kernel<128>), dim3((C + 127) / 128, (R + 127) / 128, n_outer * n_inner), dim3(256), 0, s, src, src_rs, src_so, src_si,
+                           dst, dst_rs, dst_so, dst_si, R, C, n_inner, col0);
+    else if (wide)
+        hipLaunchKernelGGL((transpose64_kernel<64>), dim3((C + 63) / 64, (R + 63) / 64, n_outer * n_inner), dim3(256), 0, s, src, src_rs, src_so, src_si, dst,
                            dst_rs, dst_so, dst_si, R, C, n_inner, col0);
     else
         hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, n_outer * n_inner), dim3(256), 0, s, src, src_rs, src_so, src_si, dst,
@@ -596,11 +636,14 @@ int vz_launch_causal_lm_loss(const float* logits, int B, int S, int V, const int
     return VZ_OK;
 }
 // `part`: vz_colsum_groups(rows) * cols floats of scratch
-int vz_colsum_groups(long rows) { return (int)(rows < 4096 ? (rows + 63) / 64 : 64); }
+int vz_colsum_groups(long rows) { return (int)(rows < 4096 ? (rows + 63) / 64 : 256); }
 int vz_launch_colsum(const bf16_t* y, int ld, long rows, int cols, float* part, float* out, hipStream_t s) {
     VZ_CHECK_ARG(y && part && out && rows > 0 && cols > 0, "colsum: bad argument");
     const int G = vz_colsum_groups(rows);
-    hipLaunchKernelGGL(colsum_part_kernel, dim3((cols + 255) / 256, G), dim3(256), 0, s, y, ld, rows, cols, part);
+    if ((cols & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)part & 15) == 0)
+        hipLaunchKernelGGL(colsum_part8_kernel, dim3((cols / 8 + 255) / 256, G), dim3(256), 0, s, y, ld, rows, cols, part);
+    else
+        hipLaunchKernelGGL(colsum_part_kernel, dim3((cols + 255) / 256, G), dim3(256), 0, s, y, ld, rows, cols, part);
     VZ_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, part, G, cols, out);
     VZ_LAUNCH_CHECK();

@@ -60,6 +60,9 @@ SYMBOLS = {
     "vz_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _P]),
     "vz_op_rmsnorm": (_I, [_P, _I, _P, _I, _P, _I, _I, _F, _P]),
     "vz_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I] + [_L] * 12 + [_F, _I, _I, _I, _P, _P]),
+    "vz_op_transpose": (_I, [_P, _L, _P, _L, _I, _I, _P]),
+    "vz_op_colsum": (_I, [_P, _I, _L, _I, _P, _L, _P, _P]),
+    "vz_op_colsum_groups": (_I, [_L]),
     "vz_op_attention_bwd": (_I, [_P] * 7 + [_I] * 7 + [_F, _I, _I, _P, _P, _L, _P]),
     "vz_op_attention_split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I] + [_L] * 12 + [_F, _I, _I, _I, _P, _P, _L, _P]),
     "vz_op_argmax": (_I, [_P, _I, _I, _P, _P]),
@@ -371,6 +374,25 @@ def rmsnorm(x, w, eps):
     check(lib().vz_op_rmsnorm(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(w), x.shape[0], x.shape[1], eps,
                               stream_ptr(x.device)))
     return y
+
+
+def transpose(x):
+    """bf16 [R, C] (unit column stride) -> contiguous [C, R] (vz_op_transpose)"""
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    y = torch.empty(x.shape[1], x.shape[0], dtype=torch.bfloat16, device=x.device)
+    check(lib().vz_op_transpose(ptr(x), x.stride(0), ptr(y), y.stride(0), x.shape[0], x.shape[1], stream_ptr(x.device)))
+    return y
+
+
+def colsum(y, out):
+    """out[c] += sum_r y[r][c]: y bf16 [rows, cols] (unit column stride), out fp32 [cols] (vz_op_colsum, the bias-gradient reduction)"""
+    _need_cuda(y, out)
+    assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and out.dtype == torch.float32 and out.is_contiguous()
+    rows, cols = y.shape
+    part = torch.empty(lib().vz_op_colsum_groups(rows) * cols, dtype=torch.float32, device=y.device)
+    check(lib().vz_op_colsum(ptr(y), y.stride(0), rows, cols, ptr(part), part.numel(), ptr(out), stream_ptr(y.device)))
+    return out
 
 
 def attention_bwd(q, k, v, dO, scale, causal=False, window=0, kv_len=None, dkv_fp32=True):
