@@ -294,6 +294,42 @@ def test_decode_matches_prefill_logits(env):
         band(f"decode step {t} logits", lg[0, 0], o16[0, S0 + t], o32[0, S0 + t])
 
 
+def test_rope_at_the_attention_q_load_is_bit_identical(env):
+    """Round 3: the prefill attention rotates the queries as it loads them from the fused QKV row (rope_kv_kernel then only rotates K and
+    appends K / V) - the same operation order as the kernel it replaces, so logits and the decode steps that follow are the same BITS as
+    with the rotated copy of Q (vz_tune_set(33, 0)).  Ragged batch with left padding (positions are not row indices there)."""
+    from vz_hip import binding as B
+    cfg, model = env["cfg"], env["model"]
+    eng = model.engine
+    synth = env["synth"]
+    for S in (40, 300):
+        ids = synth.synth_ids(S, cfg.vocab, image_pos=-1, seed=90 + S)
+        emb = eng.embed_tokens(ids).unsqueeze(0)
+        got = []
+        for knob in (1, 0):
+            try:
+                B.check(B.lib().vz_tune_set(33, knob))
+                full, last = eng.prefill(emb, [S], all_logits=True, last_logits=True)
+                eng.decode_begin(last.argmax(-1).to(torch.int32), [S], [S])
+                toks, lg = eng.decode_steps(3, return_logits=True)
+                got.append((full.clone(), lg.clone(), toks.clone()))
+            finally:
+                B.check(B.lib().vz_tune_set(33, 1))
+        assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1]) and torch.equal(got[0][2], got[1][2])
+    if eng.max_batch >= 2:
+        ids = torch.stack([synth.synth_ids(48, cfg.vocab, image_pos=-1, seed=s) for s in (5, 6)])
+        mask = torch.ones_like(ids)
+        mask[1, :17] = 0                                     # left padding on the second sample
+        outs = []
+        for knob in (1, 0):
+            try:
+                B.check(B.lib().vz_tune_set(33, knob))
+                outs.append(model(input_ids=ids.to(model.device), attention_mask=mask.to(model.device)).logits.clone())
+            finally:
+                B.check(B.lib().vz_tune_set(33, 1))
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_decode_graph_equals_eager(env):
     cfg, model = env["cfg"], env["model"]
     eng = model.engine

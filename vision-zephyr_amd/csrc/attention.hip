@@ -37,6 +37,8 @@ struct FlashParams {
     const int* kv_len;
     long long* stamps;      // profiling only (vz_tune_set(16, 1)): stage cycle counts of wave 0 of the longest causal workgroup
     float* part;            // SPLIT launches: [B][Hq][nsplit][Sq] x {o[HD], m, l}
+    const float *rope_cos, *rope_sin;   // v2, head_dim 128: RoPE applied to the queries as they are loaded (null: q is rotated already)
+    const int* rope_pos;
 };
 
 // SPLIT (Sq <= 64, no mask): blockIdx.x cuts the key tiles instead of the query rows and the workgroup leaves its
@@ -362,6 +364,29 @@ __device__ __forceinline__ void softmax_tile_defer(f32x4 (&sacc)[NT], float& m_r
     }
 }
 
+// RoPE (rotate-half) on a query row's fragments as the attention loads them: lane (c, g) holds d = ds * 32 + 8 g + j of row c, so the
+// partner d +- 64 is fragment ds +- 2 of the SAME lane.  The operation order is rope_kv_kernel's as hipcc compiles it (t = partner * sin
+// rounded, then one fused multiply-add), so the rotated bf16 values are the ones that kernel writes: bit-identical attention.
+__device__ __forceinline__ void rope_q_frags(bf16x8 (&qf)[4], const float* __restrict__ cosT, const float* __restrict__ sinT, int pos, int g) {
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+        const float* cp = cosT + (size_t)pos * 64 + ds * 32 + g * 8;
+        const float* sp = sinT + (size_t)pos * 64 + ds * 32 + g * 8;
+        const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4), s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+        bf16x8 lo = qf[ds], hi = qf[ds + 2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float cj = j < 4 ? c0[j] : c1[j - 4], sj = j < 4 ? s0[j] : s1[j - 4];
+            const float x = (float)lo[j], y = (float)hi[j];
+            float t_lo = y * sj, t_hi = x * sj;
+            asm volatile("" : "+v"(t_lo), "+v"(t_hi));          // the products are rounded on their own (no contraction into the sums below)
+            lo[j] = (__bf16)__builtin_fmaf(x, cj, -t_lo);
+            hi[j] = (__bf16)__builtin_fmaf(y, cj, t_hi);
+        }
+        qf[ds] = lo; qf[ds + 2] = hi;
+    }
+}
+
 template <int HD, bool STAMP, bool DEFER>
 __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
     constexpr int KT = 64;
@@ -421,6 +446,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn2_kernel(FlashParams p) {
         for (int ds = 0; ds < DS; ++ds) {
             qf0[ds] = *(const bf16x8*)(qp0 + ds * 32 + g * 8);
             qf1[ds] = *(const bf16x8*)(qp1 + ds * 32 + g * 8);
+        }
+        if constexpr (HD == 128) {
+            if (p.rope_cos) {
+                rope_q_frags(qf0, p.rope_cos, p.rope_sin, p.rope_pos[(size_t)b * p.Sq + qrow0], g);
+                rope_q_frags(qf1, p.rope_cos, p.rope_sin, p.rope_pos[(size_t)b * p.Sq + qrow1], g);
+            }
         }
     }
     f32x4 oacc0[DT], oacc1[DT];
@@ -795,6 +826,7 @@ int vz_attn_read_stamps(long long* host16) {          // 16 stage words + 2048 x
     return VZ_OK;
 }
 void vz_set_attn_version(int v) { g_attn_version = v; }
+int vz_attn_version() { return g_attn_version; }
 void vz_set_attn_split(int v) { g_attn_split = v; }
 
 int vz_init_attention_kernels() {
@@ -832,6 +864,9 @@ int vz_launch_attention(const AttnArgs& a, hipStream_t s) {
     p.scale = a.scale; p.causal = a.causal; p.q_pos0 = a.q_pos0; p.window = a.window; p.kv_len = a.kv_len;
     p.stamps = g_attn_stamp_on ? g_attn_stamps : nullptr;
     p.part = nullptr;
+    p.rope_cos = a.rope_cos; p.rope_sin = a.rope_sin; p.rope_pos = a.rope_pos;
+    VZ_CHECK_ARG(!a.rope_cos || (a.head_dim == 128 && a.rope_sin && a.rope_pos && g_attn_version != 1 && !a.part),
+                 "attention: RoPE at the query load is built into the head_dim-128 v2 kernel only");
     if (a.head_dim == 512 && a.part && g_attn_split != 1 && a.Sq <= 64 && !a.causal && !a.kv_len) {
         // the split is a function of Sk alone (three 32-key tiles per workgroup): a query row's result never depends on how many
         // tiles or samples share the launch (tests/test_stages_gpu.py::test_continuous_batching_matches_static_batches)

@@ -148,12 +148,13 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const bf16_t* __restrict__
     // 16 lanes per (token, head): lane `sub` owns the 8 elements d0 = (sub>>3)*64 + (sub&7)*8 .. +7 (one 16-byte access);
     // the rotation partner (d +- 64) lives in lane sub ^ 8.  Four items per wave, 16 per workgroup.
     const int lane = threadIdx.x & 63, sub = lane & 15;
-    const int heads = Hq + 2 * Hkv;
+    // q_out == nullptr: the queries are rotated by their consumer (the prefill attention's Q load) - only the K and V heads are items
+    const int heads = q_out ? Hq + 2 * Hkv : 2 * Hkv, h_first = q_out ? 0 : Hq;
     const long item = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
     const long n_items = (long)B * S * heads;
     const bool live = item < n_items;
     const long it = live ? item : n_items - 1;          // keep every lane in the shuffles below
-    const int tok = (int)(it / heads), h = (int)(it % heads);
+    const int tok = (int)(it / heads), h = h_first + (int)(it % heads);
     const int b = tok / S;
     const int d0 = (sub >> 3) * 64 + (sub & 7) * 8;
     const bf16_t* src = qkv + (size_t)tok * ld + (size_t)h * D + d0;
@@ -432,7 +433,7 @@ int vz_launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const float*
 int vz_launch_rope_kv(const bf16_t* qkv, int ld, bf16_t* q_out, bf16_t* kc, bf16_t* vc, const float* cosT, const float* sinT,
                       const int* pos, const int* slot, int B, int S, int Hq, int Hkv, int D, int max_ctx, hipStream_t s) {
     VZ_CHECK_ARG(D == 128, "rope: head_dim %d unsupported (Zephyr uses 128)", D);
-    const long items = (long)B * S * (Hq + 2 * Hkv);
+    const long items = (long)B * S * (q_out ? Hq + 2 * Hkv : 2 * Hkv);
     hipLaunchKernelGGL(rope_kv_kernel, dim3((int)((items + 15) / 16)), dim3(256), 0, s, qkv, ld, q_out, kc, vc, cosT, sinT, pos, slot, B,
                        S, Hq, Hkv, D, max_ctx);
     VZ_LAUNCH_CHECK();

@@ -863,6 +863,7 @@ extern "C" int vz_embed_splice(vz_engine* e, const int* d_kind, const int* d_idx
 // call sites through RCCL (all-reduce over one rank = identity, all-gather = copy), so the collective plumbing - library,
 // dtypes, in-place buffers, stream order, the vocab-parallel gather + repack - runs on a single GPU.
 static int g_force_comm = 0;
+static int g_rope_in_attn = 1;     // vz_tune_set(33, 0): the prefill writes a rotated copy of Q (rope_kv_kernel) for the attention again (A/B; bit-identical)
 static int g_flash_bwd = 1;               // vz_tune_set(32, 0): the training step's head-128 attention backward through the materialising batched-GEMM route again (A/B; train_engine.inc)
 static int g_attn_o = 1;           // vz_tune_set(30, 0): batch-1 decode attention and O projection as two launches again (attn_o_fused.hip off)
 static int g_persist_decode = 0;   // vz_tune_set(28, 1): batch-1 decode steps as one resident grid per token (decode_persist.hip) instead of the launch chain.
@@ -1086,13 +1087,16 @@ extern "C" int vz_llm_prefill_rows(vz_engine* e, int row0, const void* d_embeds,
     for (int i = 0; i < c.n_layers; ++i) {
         const std::string p = "llm." + std::to_string(i) + ".";
         RC(plin(x, WF(p + "in_norm", H), p + "qkv", QKV, H, qkv, QKV, nullptr, VZ_ACT_NONE));
-        { ProfScope ps(e, K_OTHER, s); RC(vz_launch_rope_kv(qkv, QKV, q, kc_of(e, i) + row_off, vc_of(e, i) + row_off, e->cosT, e->sinT, d_pos, d_slot, B, S, Hq, Hkv, D, c.max_ctx, s)); }
+        // RoPE of K + the KV append; the queries are rotated by the attention's own Q load (g_rope_in_attn; else a rotated copy q as before)
+        const bool rope_q_late = g_rope_in_attn && D == 128 && vz_attn_version() != 1;
+        { ProfScope ps(e, K_OTHER, s); RC(vz_launch_rope_kv(qkv, QKV, rope_q_late ? nullptr : q, kc_of(e, i) + row_off, vc_of(e, i) + row_off, e->cosT, e->sinT, d_pos, d_slot, B, S, Hq, Hkv, D, c.max_ctx, s)); }
         {
             ProfScope ps(e, K_ATTN, s);
             AttnArgs a;
-            a.q = q; a.k = kc_of(e, i) + row_off; a.v = vc_of(e, i) + row_off; a.o = att;
+            a.q = rope_q_late ? qkv : q; a.k = kc_of(e, i) + row_off; a.v = vc_of(e, i) + row_off; a.o = att;
             a.B = B; a.Sq = S; a.Sk = S; a.Hq = Hq; a.Hkv = Hkv; a.head_dim = D;
-            a.q_bs = (long)S * A; a.q_ss = A; a.q_hs = D;
+            a.q_bs = rope_q_late ? (long)S * QKV : (long)S * A; a.q_ss = rope_q_late ? QKV : A; a.q_hs = D;
+            if (rope_q_late) { a.rope_cos = e->cosT; a.rope_sin = e->sinT; a.rope_pos = d_pos; }
             a.k_bs = a.v_bs = (long)Hkv * c.max_ctx * D; a.k_ss = a.v_ss = D; a.k_hs = a.v_hs = (long)c.max_ctx * D;
             a.o_bs = (long)S * A; a.o_ss = A; a.o_hs = D;
             a.scale = 0.08838834764831845f;  // 128^-0.5
@@ -1505,6 +1509,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 30) { g_attn_o = value; return VZ_OK; }
     if (knob == 31) { g_attn_o_delay = value; return VZ_OK; }
     if (knob == 32) { g_flash_bwd = value; return VZ_OK; }
+    if (knob == 33) { g_rope_in_attn = value; return VZ_OK; }
     if (knob == 26) { vz_set_splitk_mid(value); return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }

@@ -227,9 +227,14 @@ struct AttnArgs {
     // head_dim 512) split the keys over several workgroups and merge the partial softmaxes in a second kernel
     float* part = nullptr;
     size_t part_floats = 0;
+    // optional (head_dim 128, the v2 kernel): q holds UNROTATED queries (e.g. the Q part of a fused QKV row) and the kernel applies RoPE
+    // while it loads them - rope_pos[b * Sq + row] indexes the [pos][64] cos / sin tables; rope_kv_kernel's arithmetic, bit for bit
+    const float *rope_cos = nullptr, *rope_sin = nullptr;
+    const int* rope_pos = nullptr;
 };
 int vz_launch_attention(const AttnArgs& a, hipStream_t s);
 void vz_set_attn_version(int v);
+int vz_attn_version();
 void vz_set_attn_split(int v);
 
 // decode attention: one query token per slot against the KV cache; lengths live on the device
