@@ -429,7 +429,11 @@ int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_strea
  *  21  fp8 tile GEMM choice [0 = by grid size; 1 = 128^2; 2 = 256^2]                22  rows from which vz_engine_prefill_fp8 engines take the fp8 MFMA [768]
  *  23  key split of few-row head_dim-512 attention [0 = every 96 keys; 1 = never; n >= 2 = n splits]
  *  24  most K slices of an M <= 512 linear [8]                                      25  Q-Former cross-attention K|V of all blocks as one GEMM [1]
- *  26  K slices for tile-GEMM grids that leave a CU one workgroup (M > 512, < 256 tiles) [1; 0 = whole-K tiles: batch-invariant] */
+ *  26  K slices for tile-GEMM grids that leave a CU one workgroup (M > 512, < 256 tiles) [1; 0 = whole-K tiles: batch-invariant]
+ *  27  K splits of the e4m3 17..64-row stream [0 = by shape]                        28  batch-1 decode steps as ONE resident grid per token (decode_persist.hip) [0]
+ *  29  one-shot all-reduce for the TP decode step when peer areas are attached [1]   30  batch-1 decode attention + O projection as one launch (attn_o_fused.hip) [1]
+ *  31  that launch's O role: wait (x ~0.2 us) before it requests its weights [12]    32  training step: tile-resident attention backward for head_dim 128 [1]
+ *  33  prefill: RoPE of the queries inside the attention's Q load [1; 0 = a rotated copy of Q from rope_kv_kernel; bit-identical] */
 int vz_tune_set(int knob, int value);
 
 /* per-kernel-class timing of the engine's launches with HIP events on the launch stream (bench.py's roofline

@@ -12,7 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _model(n_layers, max_ctx):
+def _model(n_layers, max_ctx, weight_fp8=False):
     from vz_hip import synth
     from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
     cfg = synth.ArchConfig(n_layers=n_layers)
@@ -22,7 +22,7 @@ def _model(n_layers, max_ctx):
     hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
     hf.mm_patch_merge_type = "flat"
     hf.mm_hidden_size = 5120
-    return cfg, synth, VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=max_ctx, max_tiles=1, max_text=max_ctx)
+    return cfg, synth, VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=max_ctx, max_tiles=1, max_text=max_ctx, weight_fp8=weight_fp8)
 
 
 def _knob(v):
@@ -119,6 +119,20 @@ def test_expired_hand_off_ends_the_launch_and_raises(small):
         ids2, lg2, _ = _steps(model, emb, 2, persist=1)
         assert torch.equal(ids2, ids_ref) and torch.equal(lg2, lg_ref)
     assert B.VZ_ASYNC_PERSIST == 3
+
+
+@pytest.fixture(scope="module")
+def small_fp8():
+    cfg, synth, model = _model(2, 2300, weight_fp8=True)
+    yield cfg, synth, model
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("S", [5, 300, 2200])
+def test_fused_attention_o_launch_on_e4m3_weights(small_fp8, S):
+    """the e4m3 instantiation (W8A16 engines: the O projection's 1-byte rows + per-row scales, gemv_bf16_kernel<.., FP8>'s chunk order) = the two launches"""
+    test_fused_attention_o_launch_equals_the_two_launches(small_fp8, S)
 
 
 @pytest.mark.parametrize("S", [5, 127, 300, 1100, 2200])

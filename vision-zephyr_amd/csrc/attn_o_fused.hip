@@ -34,6 +34,8 @@ constexpr int SPIN_CAP = 400000;
 struct AoParams {
     FusedParams at;                      // attention (o = the hand-off vector [4096] bf16)
     const bf16_t* o_w;                   // [4096][4096]
+    const unsigned char* o_w8;           // FP8 instantiation: e4m3 rows [4096][4096 bytes] + one 2^e scale per row (gemv.hip's W8A16 stream)
+    const float* o_scale;
     bf16_t* x;                           // residual stream [4096]: x += att . o_w^T (in place)
     unsigned* done;                      // arrival word of the mergers
     const int* step;                     // device-side step counter of the decode call
@@ -51,11 +53,23 @@ __device__ __forceinline__ float dot8(const u32x4 w, const u32x4 x, float acc) {
     return acc;
 }
 
+// 16 e4m3 weights of one lane -> 16 bf16 (k order preserved; exact) - gemv.hip's conversion
+__device__ __forceinline__ void fp8x16_to_bf16(const u32x4 w, u32x4& lo, u32x4& hi) {
+    auto cv = [](unsigned v, bool hi_half) {
+        return hi_half ? __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, true))
+                       : __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, false));
+    };
+    const unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    lo = (u32x4){cv(w0, false), cv(w0, true), cv(w1, false), cv(w1, true)};
+    hi = (u32x4){cv(w2, false), cv(w2, true), cv(w3, false), cv(w3, true)};
+}
+
 union AoShared {
     Shared attn;
     struct { __attribute__((aligned(16))) bf16_t att[OH]; int ok; } o;
 };
 
+template <bool FP8>
 __global__ __launch_bounds__(256, 3) void attn_o_fused_kernel(AoParams p) {      // 3 waves per SIMD = 3 blocks per CU: <= 168 registers
     __shared__ AoShared sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,13 +88,20 @@ __global__ __launch_bounds__(256, 3) void attn_o_fused_kernel(AoParams p) {     
     const int ob = blockIdx.x - n_attn;
     const int r0 = (ob * 4 + wave) * 2;
     for (int i = 0; i < p.delay; ++i) __builtin_amdgcn_s_sleep(8);
-    u32x4 w[2][8];
-    {
+    constexpr int NC = FP8 ? 4 : 8;                          // 16-byte pieces per lane and row: 8 x 8 bf16 or 4 x 16 e4m3
+    u32x4 w[2][NC];
+    if constexpr (FP8) {
+        const unsigned char* wp = p.o_w8 + (size_t)r0 * OH + lane * 16;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) w[r][c] = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)r * OH + c * 1024));
+    } else {
         const bf16_t* wp = p.o_w + (size_t)r0 * OH + lane * 8;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) w[r][c] = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)r * OH + c * 512));
+            for (int c = 0; c < NC; ++c) w[r][c] = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)r * OH + c * 512));
     }
     const unsigned resid = *(const unsigned*)(p.x + r0);       // x[r0], x[r0 + 1]
     const unsigned target = ((unsigned)p.step[0] * (unsigned)p.n_layers + (unsigned)p.layer + 1u) * (unsigned)p.at.Hkv;
@@ -104,15 +125,30 @@ __global__ __launch_bounds__(256, 3) void attn_o_fused_kernel(AoParams p) {     
     }
     __syncthreads();
     float acc[2] = {0.f, 0.f};
+    if constexpr (FP8) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const u32x4 xv = *(const u32x4*)(sm.o.att + c * 512 + lane * 8);
+        for (int c = 0; c < NC; ++c) {                       // gemv_bf16_kernel<.., FP8>'s chunk order and lane -> k assignment (1024 k per chunk, 16 per lane)
+            const u32x4 x0 = *(const u32x4*)(sm.o.att + c * 1024 + lane * 16), x1 = *(const u32x4*)(sm.o.att + c * 1024 + lane * 16 + 8);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) acc[r] = dot8(w[r][c], xv, acc[r]);
+            for (int r = 0; r < 2; ++r) {
+                u32x4 wl, wh;
+                fp8x16_to_bf16(w[r][c], wl, wh);
+                acc[r] = dot8(wh, x1, dot8(wl, x0, acc[r]));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const u32x4 xv = *(const u32x4*)(sm.o.att + c * 512 + lane * 8);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[r] = dot8(w[r][c], xv, acc[r]);
+        }
     }
     const float s0 = wave_sum_lane63(acc[0]), s1 = wave_sum_lane63(acc[1]);
     if (lane == 63) {
-        float t0 = s0 + bf16_to_f32((unsigned short)(resid & 0xffffu)), t1 = s1 + bf16_to_f32((unsigned short)(resid >> 16));
+        float t0 = s0, t1 = s1;
+        if constexpr (FP8) { t0 *= p.o_scale[r0]; t1 *= p.o_scale[r0 + 1]; }       // the row's power-of-two scale, once per output
+        t0 += bf16_to_f32((unsigned short)(resid & 0xffffu)); t1 += bf16_to_f32((unsigned short)(resid >> 16));
         if (!sm.o.ok) t0 = t1 = __uint_as_float(0x7fc00000u);          // an expired wait never passes for a result
         *(unsigned*)(p.x + r0) = pack_bf16x2(t0, t1);
     }
@@ -121,16 +157,17 @@ __global__ __launch_bounds__(256, 3) void attn_o_fused_kernel(AoParams p) {     
 }  // namespace
 
 int g_attn_o_delay = 12;      // vz_tune_set(31, n): the O role waits n x ~0.21 us before requesting its weights, so that the attention blocks' K / V loads reach the memory system first (scan at ctx 2048: 0 -> 344, 8 -> 346, 12 -> 357, 16 -> 352, 24 -> 348 tok/s)
-int vz_launch_attn_o_fused(const AttnDecodeFusedArgs& a, const bf16_t* o_w, bf16_t* att_scratch, bf16_t* x, unsigned* done, const int* step,
-                           int layer, int n_layers, int* err, hipStream_t s) {
+int vz_launch_attn_o_fused(const AttnDecodeFusedArgs& a, const bf16_t* o_w, const unsigned char* o_w8, const float* o_scale, bf16_t* att_scratch,
+                           bf16_t* x, unsigned* done, const int* step, int layer, int n_layers, int* err, hipStream_t s) {
     VZ_CHECK_ARG(a.B == 1 && a.D == D && a.Hq == 32 && a.Hkv == 8 && a.nsplit >= 1 && a.nsplit <= 32, "attn_o_fused: batch 1, 32 / 8 heads of 128, <= 32 context splits");
-    VZ_CHECK_ARG(a.qkv && a.kc && a.vc && att_scratch && a.part && a.ticket && o_w && x && done && step && err, "attn_o_fused: null argument");
+    VZ_CHECK_ARG(a.qkv && a.kc && a.vc && att_scratch && a.part && a.ticket && (o_w || (o_w8 && o_scale)) && x && done && step && err, "attn_o_fused: null argument");
     AoParams p;
     p.at.qkv = a.qkv; p.at.kc = a.kc; p.at.vc = a.vc; p.at.o = att_scratch; p.at.part = a.part; p.at.ticket = a.ticket;
     p.at.cosT = a.cosT; p.at.sinT = a.sinT; p.at.pos = a.pos; p.at.slot = a.slot;
     p.at.B = 1; p.at.Hq = a.Hq; p.at.Hkv = a.Hkv; p.at.max_ctx = a.max_ctx; p.at.nsplit = a.nsplit; p.at.window = a.window; p.at.scale = a.scale;
-    p.o_w = o_w; p.x = x; p.done = done; p.step = step; p.err = err; p.layer = layer; p.n_layers = n_layers; p.delay = g_attn_o_delay;
-    hipLaunchKernelGGL(attn_o_fused_kernel, dim3(a.nsplit * a.Hkv + O_BLOCKS), dim3(256), 0, s, p);
+    p.o_w = o_w; p.o_w8 = o_w8; p.o_scale = o_scale; p.x = x; p.done = done; p.step = step; p.err = err; p.layer = layer; p.n_layers = n_layers; p.delay = g_attn_o_delay;
+    if (o_w8 && o_scale) hipLaunchKernelGGL(attn_o_fused_kernel<true>, dim3(a.nsplit * a.Hkv + O_BLOCKS), dim3(256), 0, s, p);      // e4m3 rows take precedence (as in linear())
+    else hipLaunchKernelGGL(attn_o_fused_kernel<false>, dim3(a.nsplit * a.Hkv + O_BLOCKS), dim3(256), 0, s, p);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }

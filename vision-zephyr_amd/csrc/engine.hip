@@ -1228,7 +1228,7 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
         { ProfScope ps(e, K_OTHER, s); RC(vz_launch_embed_tokens(cur, B, H, WB("llm.embed", (long)c.vocab * H), x, s)); }
         for (int i = 0; i < c.n_layers; ++i) {
             const std::string p = "llm." + std::to_string(i) + ".";
-            const bool fuse_ao = g_attn_o && B == 1 && e->tp == 1 && tp_local(e) && !c.weight_fp8 && H == 4096 && A == 4096 && Hq == 32 && Hkv == 8 &&
+            const bool fuse_ao = g_attn_o && B == 1 && e->tp == 1 && tp_local(e) && H == 4096 && A == 4096 && Hq == 32 && Hkv == 8 &&
                                  D == 128 && e->dec_nsplit <= 32 && e->d_ao_done;
             RC(linear(e, 1, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps,
                       W8(p + "qkv.w8", (long)QKV * H), WS(p + "qkv.ws", QKV)));
@@ -1243,8 +1243,10 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
                     // batch 1 (round 3): the O projection's workgroups ride in the attention's grid and stream their weights under its latency
                     // chain (attn_o_fused.hip); same arithmetic as the two launches, bit for bit
                     const bf16_t* ow = WB(p + "o.w", (long)H * A);
+                    const unsigned char* ow8 = W8(p + "o.w8", (long)H * A);        // a weight_fp8 engine: the e4m3 rows + scales (as linear() would take them)
+                    const float* ows = WS(p + "o.ws", H);
                     if (rc) return rc;
-                    RC(vz_launch_attn_o_fused(a, ow, att, x, e->d_ao_done, step, i, c.n_layers, e->d_ferr, s));
+                    RC(vz_launch_attn_o_fused(a, ow, ow8, ows, att, x, e->d_ao_done, step, i, c.n_layers, e->d_ferr, s));
                 } else {
                     RC(vz_launch_attn_decode_fused(a, s));
                 }

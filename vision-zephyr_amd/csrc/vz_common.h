@@ -302,8 +302,8 @@ struct AttnDecodeFusedArgs {
 int vz_launch_attn_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s);
 // attn_o_fused.hip: the same attention + the O projection (x += att . o_w^T, batch 1) in one launch; `done` = a zeroed device word,
 // `step` = the decode call's device-side step counter
-int vz_launch_attn_o_fused(const AttnDecodeFusedArgs& a, const bf16_t* o_w, bf16_t* att_scratch, bf16_t* x, unsigned* done, const int* step,
-                           int layer, int n_layers, int* err, hipStream_t s);
+int vz_launch_attn_o_fused(const AttnDecodeFusedArgs& a, const bf16_t* o_w, const unsigned char* o_w8, const float* o_scale, bf16_t* att_scratch,
+                           bf16_t* x, unsigned* done, const int* step, int layer, int n_layers, int* err, hipStream_t s);
 
 
 int vz_launch_rope_kv(const bf16_t* qkv, int ld, bf16_t* q_out, bf16_t* kc, bf16_t* vc, const float* cosT,
