@@ -197,10 +197,6 @@ def bench_gemm():
         us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act), 12) for _ in range(3))
         B.check(B.lib().vz_tune_set(11, 0))
         row.append(f"drain-wait: {us:8.1f} us")
-        B.check(B.lib().vz_tune_set(11, 2))          # experiment: the 256^2 kernel's fast epilogue without its stores (what a better store pattern could win at most)
-        us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act), 12) for _ in range(3))
-        B.check(B.lib().vz_tune_set(11, 0))
-        row.append(f"no-stores: {us:8.1f} us")
         print(f"gemm {name:12s} M{M} N{N} K{K}: " + "   ".join(row), flush=True)
 
 

@@ -22,15 +22,19 @@ w = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
 if os.environ.get("VZ_ZERO", "0") == "1":      # all-zero operands: the clock the chip holds when the data toggles nothing (guide: DVFS give-back item 1)
     x.zero_(); w.zero_()
 B.check(B.lib().vz_tune_set(4, sk))
+for kv in filter(None, os.environ.get("VZ_TUNE", "").split(",")):       # experiments: "knob=value,..." (34=0: direct fragment-shaped epilogue stores)
+    _k, _v = (int(t) for t in kv.split("="))
+    B.check(B.lib().vz_tune_set(_k, _v))
+ACT = int(os.environ.get("VZ_ACT", "0"))
 import time
 t_end = time.time() + 1.0
 while time.time() < t_end:                 # let DVFS settle under this kernel's load
     for _ in range(50):
-        B.linear(x, w, impl=2)
+        B.linear(x, w, impl=2, act=ACT)
     torch.cuda.synchronize()
 B.check(B.lib().vz_tune_set(6, 1))
 for _ in range(3):
-    B.linear(x, w, impl=2)
+    B.linear(x, w, impl=2, act=ACT)
 torch.cuda.synchronize()
 buf = (C.c_longlong * (4096 * 16))()
 n = C.c_int(0)

@@ -159,7 +159,6 @@ __device__ __forceinline__ f32x4 act4(f32x4 v) {
 }
 
 __device__ __forceinline__ void put4(const Gemm256Params& p, bool has_res, bool f32, int m, int n0, f32x4 v) {
-    if (p.drain == 2 && m >= 0) return;          // EXPERIMENT (vz_tune_set(11, 2)): epilogue without its stores - bounds what a better store pattern could win
     if (has_res) {
         const u16x4 rr = *(const u16x4*)(p.residual + (size_t)m * p.ldr + n0);
         v[0] += bf16_to_f32(rr[0]); v[1] += bf16_to_f32(rr[1]); v[2] += bf16_to_f32(rr[2]); v[3] += bf16_to_f32(rr[3]);
@@ -604,7 +603,7 @@ __device__ __forceinline__ void gemm256_body(Gemm256Params p) {
             epilogue_rows<1, 3>(p, acc, m_base, n_base, g, swiglu, n_out_total, vec_ok);
             }
         }
-        if ((p.stamps || p.drain == 1) && seg_no < 3) {       // profiling only: the stamp is taken once the stores have drained
+        if ((p.stamps || p.drain) && seg_no < 3) {       // profiling only: the stamp is taken once the stores have drained
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             VZ_STAMP(4 + seg_no * 5)
             if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 5 + seg_no * 5] = ((long long)nks << 32) | (finish ? 1 : 0) | (nks != nk ? 2 : 0);
