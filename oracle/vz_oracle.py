@@ -281,6 +281,40 @@ def quantize_state_dict(sd):
     return out
 
 
+# NF4 (`load_4bit`): CPU restatement of bitsandbytes' published nf4 quantiser (QLoRA appendix E; blocksize 64, nearest level, fp32 absmax -
+# the double quantisation of the absmax values is NOT restated; bitsandbytes is not in the reference tree nor installed: parity unpinned)
+_NF4 = (-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635, -0.18477343022823334,
+        -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725, 0.24611230194568634, 0.33791524171829224,
+        0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0)
+
+
+def fake_quantize_nf4(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] -> nearest NF4 level * absmax per block of 64 consecutive row elements (fp32); plain loops over the levels, no bucketize"""
+    w = w.float()
+    N, K = w.shape
+    x = w.reshape(N, K // 64, 64)
+    absmax = x.abs().amax(dim=2, keepdim=True)
+    xn = x / torch.clamp(absmax, min=1e-30)
+    best = torch.full_like(xn, _NF4[0])
+    err = (xn - _NF4[0]).abs()
+    for lv in _NF4[1:]:                                   # ascending levels, strict improvement: a tie keeps the LOWER level
+        e = (xn - lv).abs()
+        take = e < err
+        best = torch.where(take, torch.full_like(xn, lv), best)
+        err = torch.where(take, e, err)
+    return (best * absmax).reshape(N, K)
+
+
+def quantize_state_dict_nf4(sd):
+    """the model a weight_nf4 engine computes with: the decoder layers' seven linears NF4-quantised from their bf16 values and rounded
+    back to bf16; lm_head, embeddings, norms, CLIP and the Q-Former untouched (bitsandbytes' default skip list keeps lm_head)."""
+    out = dict(sd)
+    for k, v in sd.items():
+        if k.startswith("model.layers.") and k.endswith(_FP8_KEYS):
+            out[k] = fake_quantize_nf4(v.bfloat16().float()).bfloat16().float()
+    return out
+
+
 # ================================================================================================
 # a6/a7: embedding splice  (ref:vis_zephyr/model/vis_zephyr_arch.py:129-333,396-530)
 # ================================================================================================

@@ -114,8 +114,39 @@ def test_loader_rejects_what_the_engine_cannot_do():
     from vis_zephyr.model.builder import load_pretrained_model
     with pytest.raises(ValueError):
         load_pretrained_model("x", None, "llava-7b")
-    with pytest.raises(NotImplementedError):
-        load_pretrained_model("x", None, "vis-zephyr-7b", load_4bit=True)
+
+
+def test_nf4_quantiser_restatements_agree():
+    """`load_4bit` (ref:vis_zephyr/model/builder.py:35-43 -> bitsandbytes nf4, blocksize 64): the engine-side quantiser (vz_hip/quant.py,
+    torch.bucketize on the level midpoints) and the oracle's (plain loop over the 16 levels) are two restatements of the published algorithm -
+    equal bit for bit on random weights, on the levels themselves, on ties and on an all-zero block.  Parity against bitsandbytes itself is
+    unpinned (not vendored in the reference, not installed here); its double quantisation of the block scales is not restated."""
+    import os
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    from oracle import vz_oracle as O
+    from vz_hip import quant
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(48, 512, generator=g) * 0.03).bfloat16().float()
+    a, b = quant.fake_quantize_nf4(w), O.fake_quantize_nf4(w)
+    assert torch.equal(a, b)
+    rel = float((a - w).norm() / w.norm())
+    assert 0.05 < rel < 0.13                                  # 4-bit normal-float on Gaussian weights: ~9 %
+    lv = torch.tensor([list(quant.NF4_LEVELS) * 4]) * 0.37   # one block per 64: absmax 0.37, every element ON a level
+    codes, absmax = quant.nf4_quantize(lv)
+    assert codes[0, :16].tolist() == list(range(16)) and torch.allclose(absmax, torch.full_like(absmax, 0.37))
+    assert torch.allclose(quant.nf4_dequantize(codes, absmax), lv, rtol=0, atol=1e-7) and torch.equal(O.fake_quantize_nf4(lv), quant.fake_quantize_nf4(lv))
+    mid = torch.zeros(1, 64)
+    mid[0, 0] = 1.0
+    mid[0, 1] = (quant.NF4_LEVELS[9] + quant.NF4_LEVELS[10]) / 2          # a tie goes to the lower level in both
+    assert torch.equal(quant.fake_quantize_nf4(mid), O.fake_quantize_nf4(mid))
+    z = torch.zeros(2, 128)
+    assert torch.equal(quant.fake_quantize_nf4(z), z) and torch.equal(O.fake_quantize_nf4(z), z)
+    # rows are independent and blocks never straddle them: stacking q / k / v before quantising changes nothing
+    q, k = w[:16], w[16:48]
+    assert torch.equal(quant.fake_quantize_nf4(torch.cat([q, k])), torch.cat([quant.fake_quantize_nf4(q), quant.fake_quantize_nf4(k)]))
 
 
 def test_prepare_inputs_for_generation_reattaches_images():

@@ -25,8 +25,9 @@ class _Tok:            # stands in for the sentencepiece tokenizer (no tokenizer
         return self.n
 
 
-@pytest.mark.parametrize("load_8bit", [False, True])
-def test_load_pretrained_model_matches_from_synthetic(tmp_path, monkeypatch, load_8bit):
+@pytest.mark.parametrize("mode", ["bf16", "8bit", "4bit"])
+def test_load_pretrained_model_matches_from_synthetic(tmp_path, monkeypatch, mode):
+    load_8bit, load_4bit = mode == "8bit", mode == "4bit"
     from safetensors.torch import save_file
     import transformers
     from vz_hip import synth
@@ -63,9 +64,9 @@ def test_load_pretrained_model_matches_from_synthetic(tmp_path, monkeypatch, loa
                "mm_vision_select_layer": "-2,-5,-8,-11,6", "mm_projector_type": "mlp2x_gelu", "eos_token_id": 2, "pad_token_id": 2,
                "bos_token_id": 1}, open(ckpt / "config.json", "w"))
     monkeypatch.setattr(transformers.AutoTokenizer, "from_pretrained", staticmethod(lambda *a, **k: _Tok(300)))
-    tok, model, proc, ctx = load_pretrained_model(str(ckpt), str(base), "vis-zephyr-7b-v1-pretrain", load_8bit=load_8bit, max_ctx=256)
+    tok, model, proc, ctx = load_pretrained_model(str(ckpt), str(base), "vis-zephyr-7b-v1-pretrain", load_8bit=load_8bit, load_4bit=load_4bit, max_ctx=256)
     assert ctx == 2048 and len(tok) == 301 and tok.added == ["<im_patch>"]        # ref builder.py:141-153: vocabulary grows by one
-    assert model.config.vocab_size == 301 and model.engine.cfg.vocab == 301 and model.engine.weight_fp8 == load_8bit
+    assert model.config.vocab_size == 301 and model.engine.cfg.vocab == 301 and model.engine.weight_fp8 == load_8bit and model.engine.weight_nf4 == load_4bit
     assert proc is not None and proc.crop_size["height"] == 336
     hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=1, num_attention_heads=cfg.n_heads,
                          num_key_value_heads=cfg.n_kv_heads, vocab_size=300, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
@@ -73,7 +74,7 @@ def test_load_pretrained_model_matches_from_synthetic(tmp_path, monkeypatch, loa
     hf.mm_vision_tower = str(clip)
     hf.mm_patch_merge_type = "flat"
     hf.mm_hidden_size = 5120
-    ref = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=256, max_tiles=2, max_text=64, weight_fp8=load_8bit)
+    ref = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=256, max_tiles=2, max_text=64, weight_fp8=load_8bit, weight_nf4=load_4bit)
     tiles = synth.synth_tiles(2, seed=1).to(model.device).bfloat16()
     ids = synth.synth_ids(20, 300, image_pos=3, seed=2).unsqueeze(0).to(model.device)
     diff = [n for n, t in ref.engine.w.items() if not n.startswith(("llm.embed", "llm.lm_head")) and not torch.equal(t, model.engine.w[n])]

@@ -456,6 +456,52 @@ def test_resize_token_embeddings_live(env):
     assert torch.equal(model(input_ids=ids).logits, before)
 
 
+def test_nf4_weight_engine_matches_quantized_oracle(env):
+    """`load_4bit` of the drop-in builder (ref:vis_zephyr/model/builder.py:35-43): the decoder layers' linears NF4-quantised at load time
+    (64-element blocks, vz_hip/quant.py), every kernel computing on the dequantised bf16 values.  Against the oracle running the
+    identically quantised state dict: engine tensors bit-equal, prefill logits inside the bf16 band, the quantisation visible against the
+    unquantised oracle, decode = prefill under teacher forcing.  (Parity against bitsandbytes itself: unpinned, see vz_hip/quant.py.)"""
+    from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
+    O, sd, synth, cfg = env["O"], env["sd"], env["synth"], env["cfg"]
+    hf = VisZephyrConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.n_layers,
+                         num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab,
+                         rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, sliding_window=cfg.sliding_window,
+                         eos_token_id=2, pad_token_id=2, bos_token_id=1)
+    hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
+    hf.mm_patch_merge_type = "flat"
+    hf.mm_hidden_size = 5120
+    model = VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=256, max_tiles=1, max_text=64, weight_nf4=True)
+    eng = model.engine
+    sdq = O.quantize_state_dict_nf4(sd)
+    qkv = torch.cat([sdq[f"model.layers.1.self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+    assert torch.equal(eng.w["llm.1.qkv.w"].float().cpu(), qkv)
+    g = eng.w["llm.0.gu.w"].float().cpu().view(-1, 2, 16, cfg.hidden)
+    assert torch.equal(g[:, 0].reshape(-1, cfg.hidden), sdq["model.layers.0.mlp.gate_proj.weight"])
+    assert torch.equal(eng.w["llm.lm_head"].float().cpu(), sd["lm_head.weight"].bfloat16().float())          # not quantised (skip list)
+    # 16 levels x one scale per block: at most 16 distinct |values| / absmax in a block
+    blk = eng.w["llm.0.down.w"][5, :64].float()
+    assert len(torch.unique((blk / blk.abs().max()).round(decimals=3))) <= 16
+    ids = synth.synth_ids(40, cfg.vocab, image_pos=-1, seed=9)
+    lo_bf, _ = O.llm_forward(cfg, sdq, O.embed_tokens(sd, ids.unsqueeze(0), O.BF16), P=O.BF16)
+    lo_32, _ = O.llm_forward(cfg, sdq, O.embed_tokens(sd, ids.unsqueeze(0), O.FP32), P=O.FP32)
+    emb = eng.embed_tokens(ids).unsqueeze(0)
+    full, _ = eng.prefill(emb, [40], all_logits=True, last_logits=False)
+    band("nf4 prefill logits", full, lo_bf, lo_32)
+    lo_unq, _ = O.llm_forward(cfg, sd, O.embed_tokens(sd, ids.unsqueeze(0), O.FP32), P=O.FP32)
+    assert errs(full, lo_unq)[1] > 2 * errs(full, lo_32)[1]
+    S0 = 33
+    eng.prefill(emb[:, :S0].contiguous(), [S0], all_logits=False, last_logits=True)
+    eng.decode_begin(ids[S0:S0 + 1].to(torch.int32), [S0], [S0])
+    _, lg = eng.decode_steps(1, return_logits=True)
+    band("nf4 decode step logits", lg[0, 0], lo_bf[0, S0], lo_32[0, S0])
+    # a second finalize (e.g. after load_state_dict of new projector weights) does not quantise twice
+    before = eng.w["llm.1.qkv.w"].clone()
+    eng.finalize()
+    assert torch.equal(eng.w["llm.1.qkv.w"], before)
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_fp8_weight_engine_matches_quantized_oracle(env):
     """W8A16 (SURVEY config 5; `load_8bit` of the drop-in builder): the engine's decode GEMVs stream e4m3 weights with one
     power-of-two scale per row, its prefill GEMMs run on the bf16 copy of the same dequantised weights.  Checked against

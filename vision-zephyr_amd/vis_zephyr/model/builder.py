@@ -27,8 +27,9 @@ def _load_config(path: str) -> VisZephyrConfig:
 
 def load_pretrained_model(model_path, model_base, model_name, load_8bit: bool = False, load_4bit: bool = False,
                           device_map="auto", device="cuda", **kwargs):
-    if load_4bit:
-        raise NotImplementedError("nf4 weights are not built in the MI355X engine (bf16, or 8-bit e4m3 via load_8bit)")
+    # load_4bit: the reference hands the LLM linears to bitsandbytes as NF4 with double quantisation, fp16 compute (ref builder.py:35-43).
+    # Here: the same NF4 fake-quantisation of the decoder-layer linears (64-element blocks; absmax kept in fp32 - the double
+    # quantisation of the scales is not restated, vz_hip/quant.py) at load time, computed with by the bf16 engine.
     # load_8bit: the reference quantises the LLM linears to int8 through bitsandbytes (ref builder.py:33-34); the MI355X
     # engine's 8-bit form is W8A16 - OCP e4m3 weights with one power-of-two scale per row, streamed by the decode GEMV
     # (vz_hip/quant.py); activations and the prefill GEMMs stay bf16
@@ -57,7 +58,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit: bool = 
 
     clip_dir = W.resolve_hub_path(getattr(config, "mm_vision_tower", None), "mm_vision_tower")
     dev = "cuda:0" if device == "cuda" else device
-    model = VisZephyrForCausalLM(config, device=dev, max_ctx=kwargs.pop("max_ctx", 4096), weight_fp8=bool(load_8bit))
+    model = VisZephyrForCausalLM(config, device=dev, max_ctx=kwargs.pop("max_ctx", 4096), weight_fp8=bool(load_8bit), weight_nf4=bool(load_4bit) and not load_8bit)
     model.load_state_dict_stream(W.resize_vocab(W.iter_reference_checkpoint(model_path, model_base, clip_dir, lora=lora),
                                                 len(tokenizer)))
     tower = model.get_vision_tower()

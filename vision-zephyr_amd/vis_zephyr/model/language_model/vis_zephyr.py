@@ -108,13 +108,13 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
 
     def __init__(self, config, device: Union[str, torch.device] = "cuda:0", max_batch: int = 1,
                  max_ctx: int = 4096, max_tiles: int = 8, max_text: int = 2048, engine: Optional[Engine] = None,
-                 tp_size: int = 1, tp_rank: int = 0, weight_fp8: bool = False):
+                 tp_size: int = 1, tp_rank: int = 0, weight_fp8: bool = False, weight_nf4: bool = False):
         self.config = config
         self.arch = arch_from_config(config)
         self.engine = engine if engine is not None else Engine(self.arch, device=device, max_batch=max_batch,
                                                                max_ctx=max_ctx, max_tiles=max_tiles,
                                                                max_text=max_text, tp_size=tp_size, tp_rank=tp_rank,
-                                                               weight_fp8=weight_fp8)
+                                                               weight_fp8=weight_fp8, weight_nf4=weight_nf4)
         self.device = self.engine.device
         self.dtype = torch.bfloat16
         self.model = VisZephyrModel(config, self)
@@ -158,7 +158,7 @@ class VisZephyrForCausalLM(VisZephyrMetaForCausalLM):
         if isinstance(device_map, dict) and "" in device_map:          # ref builder.py:29-31: device_map = {"": device}
             device = device_map[""]
         dev = "cuda:0" if str(device) == "cuda" else device
-        engine_kw = {k: kw.pop(k) for k in ("max_batch", "max_ctx", "max_tiles", "max_text", "tp_size", "tp_rank", "weight_fp8") if k in kw}
+        engine_kw = {k: kw.pop(k) for k in ("max_batch", "max_ctx", "max_tiles", "max_text", "tp_size", "tp_rank", "weight_fp8", "weight_nf4") if k in kw}
         model = cls(config, device=dev, **engine_kw)
         for name, t in W.iter_backbone(path):
             model.engine.add_weight(name, t)

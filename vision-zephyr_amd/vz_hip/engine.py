@@ -39,7 +39,8 @@ def rope_tables(cfg: ArchConfig, max_pos: int) -> Tuple[torch.Tensor, torch.Tens
 
 class Engine:
     def __init__(self, cfg: ArchConfig, device="cuda:0", max_batch: int = 1, max_ctx: int = 4096,
-                 max_tiles: int = 8, max_text: int = 2048, tp_size: int = 1, tp_rank: int = 0, weight_fp8: bool = False):
+                 max_tiles: int = 8, max_text: int = 2048, tp_size: int = 1, tp_rank: int = 0, weight_fp8: bool = False,
+                 weight_nf4: bool = False):
         self.lib = B.load_library()            # raises when the HIP library is absent: no fallback
         self._qf_kv_pool = {}
         if not torch.cuda.is_available():
@@ -62,6 +63,10 @@ class Engine:
             max_tiles=max_tiles, max_text=max_text, tp_size=tp_size, tp_rank=tp_rank,
             clip_keep_cls=int(cfg.clip_keep_cls), weight_fp8=int(weight_fp8))
         self.weight_fp8 = bool(weight_fp8)
+        if weight_fp8 and weight_nf4:
+            raise ValueError("weight_fp8 and weight_nf4 are two quantisations of the same linears: pick one")
+        self.weight_nf4 = bool(weight_nf4)
+        self._nf4_done = set()
         self.prefill_fp8 = False
         h = C.c_void_p()
         B.check(self.lib.vz_engine_create(C.byref(c), C.byref(h)))
@@ -101,6 +106,7 @@ class Engine:
         """the e4m3 copy + row scales of a bf16 decode weight are derived data: whoever rewrites (or replaces) the bf16 tensor
         invalidates them, so that finalize() re-quantises (a second load_weights / LoRA re-merge / resize_vocab on a
         weight_fp8 engine must not leave decode streaming the OLD e4m3 rows)."""
+        self._nf4_done.discard(name)          # a rewritten tensor holds unquantised values again
         nt = name + "t"
         if nt in self.w:                      # the fragment-tiled copy of a bf16 decode weight (bf16 engines)
             del self.w[nt]
@@ -426,7 +432,21 @@ class Engine:
                 continue
             self.w[name + "t"] = B.tile_weights(w)
 
+    _NF4_NAMES = re.compile(r"llm\.\d+\.(qkv|o|gu|down)\.w$")       # the decoder layers' linears; lm_head stays as it is (bitsandbytes' default skip list)
+
+    def _nf4_decode_weights(self):
+        """weight_nf4 (`load_4bit`): every decoder-layer linear is replaced by its NF4 fake-quantisation (vz_hip/quant.py: 64-element
+        blocks, fp32 absmax) rounded to bf16; every kernel then runs on those values - the 4-bit model on the bf16 engine."""
+        from . import quant
+        for name in [n for n in self.w if self._NF4_NAMES.match(n) and n not in self._nf4_done]:
+            w = self.w[name]
+            w.copy_(quant.fake_quantize_nf4(w).to(torch.bfloat16))
+            self._nf4_done.add(name)
+            self._registered.discard(name)
+
     def finalize(self):
+        if self.weight_nf4:
+            self._nf4_decode_weights()
         if self.weight_fp8:
             self._quantize_decode_weights()
         if self.max_batch > (16 if self.weight_fp8 else 1):      # (an e4m3 engine streams row-major e4m3 rows up to 16 rows, the tiled e4m3 copies beyond)

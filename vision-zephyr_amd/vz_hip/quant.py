@@ -42,3 +42,47 @@ def dequantize_rows(w8: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
 def fake_quantize_rows(w: torch.Tensor) -> torch.Tensor:
     """w -> w_q in fp32 (what both the engine and the oracle compute with)."""
     return dequantize_rows(*quantize_rows(w))
+
+
+# ================================================================================================
+# NF4 (`load_4bit=True` of the drop-in builder; ref:vis_zephyr/model/builder.py:35-43 -> bitsandbytes, a third-party
+# dependency that is not vendored in the reference and not installed here: its published algorithm, QLoRA (Dettmers et al. 2023)
+# appendix E / bitsandbytes `quantize_4bit(quant_type="nf4", blocksize=64)`, restated)
+#   * the weight is cut into blocks of 64 consecutive elements of a row (in_features is a multiple of 64 for every Zephyr linear, so the
+#     flattened blocks bitsandbytes takes never straddle rows, and q / k / v or gate / up quantised apart or stacked give the same codes);
+#   * absmax = max|w| of the block; each element w / absmax goes to the NEAREST of the 16 NormalFloat-4 levels below;
+#   * dequantised value = level * absmax.
+# Not restated: `bnb_4bit_use_double_quant` - bitsandbytes then stores the absmax values themselves in 8 bits (blocks of 256, a dynamic
+# exponent code); that perturbs every block's scale by a fraction of a percent.  This build keeps absmax in fp32.  With no bitsandbytes
+# in the image there is no vector to pin either part against: parity of this option is "unpinned" (DESIGN.md section 2).
+# The engine computes on the DEQUANTISED values rounded to bf16 (`Engine(weight_nf4=True)`): the model is the 4-bit model, the kernels
+# are the bf16 ones (no 4-bit weight stream was built; SURVEY section 2.2 names fp8 as this build's quantised form).
+# ================================================================================================
+NF4_LEVELS = (-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635, -0.18477343022823334,
+              -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725, 0.24611230194568634, 0.33791524171829224,
+              0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0)
+NF4_BLOCK = 64
+
+
+def nf4_quantize(w: torch.Tensor):
+    """w [N, K] with K % 64 == 0 -> (codes uint8 [N, K] in 0..15, absmax fp32 [N, K / 64])."""
+    N, K = w.shape
+    assert K % NF4_BLOCK == 0, "NF4 blocks are 64 consecutive elements of a row"
+    x = w.detach().float().reshape(N, K // NF4_BLOCK, NF4_BLOCK)
+    absmax = x.abs().amax(dim=2)
+    levels = torch.tensor(NF4_LEVELS, dtype=torch.float32, device=w.device)
+    mid = (levels[:-1] + levels[1:]) * 0.5                       # nearest level = how many midpoints lie below
+    xn = x / torch.clamp(absmax, min=1e-30).unsqueeze(2)
+    codes = torch.bucketize(xn, mid, right=False).to(torch.uint8)
+    return codes.reshape(N, K), absmax
+
+
+def nf4_dequantize(codes: torch.Tensor, absmax: torch.Tensor) -> torch.Tensor:
+    N, K = codes.shape
+    levels = torch.tensor(NF4_LEVELS, dtype=torch.float32, device=codes.device)
+    return (levels[codes.long()].reshape(N, K // NF4_BLOCK, NF4_BLOCK) * absmax.unsqueeze(2)).reshape(N, K)
+
+
+def fake_quantize_nf4(w: torch.Tensor) -> torch.Tensor:
+    """w -> level * absmax per 64-element block, fp32."""
+    return nf4_dequantize(*nf4_quantize(w))
