@@ -486,7 +486,9 @@ int vz_launch_gemm128(const LinearArgs& a, hipStream_t s) {
     // per-tile computation, tests/test_stages_gpu.py::test_qformer).
     (void)tiles;
     if (g_splitk_mode != 1 && a.M <= 512 && p.tiles_n < 128 && a.act != VZ_ACT_SWIGLU && (a.N & 3) == 0) {
-        splitk = (256 + p.tiles_n - 1) / p.tiles_n;
+        // ~256 workgroups per row tile, rounded DOWN: two row tiles (the Q-Former's 160 rows) then fit the 512 slots in one round
+        // (N = 12288: 96 column tiles x 3 slices x 2 row tiles = 576 workgroups ran a second round - 57 us; x 2 slices: 47 us)
+        splitk = std::max(1, 256 / p.tiles_n);
         if (splitk > g_splitk_cap) splitk = g_splitk_cap;
         while (splitk > 1 && nk / splitk < 8) --splitk;
     }
