@@ -18,9 +18,10 @@ python3 $GRAFT_REPO_ROOT/tools/analyze_trace.py $(find /tmp/prof_final -name "b_
 echo "profile done"; head -8 $OUT/bench_phase_breakdown.txt
 cd $GRAFT_REPO_ROOT
 # every step unbuffered and visible as it goes (a silent step looks hung to the box's watchdog): --line-buffered greps, tee
-run() { echo "== $*" | tee -a $OUT/configs.txt; timeout -k 10 420 python -u "$@" 2>&1 | grep --line-buffered -v amdgpu.ids | grep --line-buffered "batch\|stage-1\|tiles ->\|Zephyr forward\|whole forward\|qformer" | tee -a $OUT/configs.txt; }
+run() { echo "== $*" | tee -a $OUT/configs.txt; timeout -k 10 420 python -u "$@" 2>&1 | grep --line-buffered -v amdgpu.ids | grep --line-buffered "batch\|stage-1\|tiles ->\|Zephyr forward\|whole forward\|qformer\|step time\|device memory" | tee -a $OUT/configs.txt; }
 : > $OUT/configs.txt
 run tools/bench_stage1.py
+run tools/bench_stage1.py 64 32 train 64
 run tools/bench_vcr.py
 run tools/bench_vcr.py fp8
 run tools/bench_vcr.py fp8mfma

@@ -9,7 +9,7 @@ def timed(fn, n):
     for i in range(n): fn(i)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e6
-for (M, N, K) in ((160, 4096, 4096), (160, 12288, 4096), (160, 8192, 4096), (160, 4096, 8192)):
+for (M, N, K) in ((128, 4096, 4096), (160, 4096, 4096), (128, 12288, 4096), (160, 12288, 4096), (128, 4096, 8192), (160, 4096, 8192), (32, 4096, 4096), (64, 4096, 4096)):
     x = torch.randn(M, K, device=dev).bfloat16()
     ws = [torch.randn(N, K, device=dev).bfloat16() * 0.02 for _ in range(8)]      # 8 x 33.5 MB: rotates through more than the L2s hold
     row = []
