@@ -203,7 +203,8 @@ def bench_gemm():
 def bench_gemm_square():
     """Full-round shapes: the guide quotes its 256^2 template at 4096^3 / 8192^3 on random operands."""
     shapes = [("4k^3", 4096, 4096, 4096, 0), ("8k^3", 8192, 8192, 8192, 0), ("4 rounds", 2048, 32768, 4096, 0),
-              ("3.5 rounds", 2048, 28672, 4096, 0), ("3 rounds", 2048, 24576, 4096, 0), ("down 256", 2048, 4096, 14336, 0)]
+              ("3.5 rounds", 2048, 28672, 4096, 0), ("3 rounds", 2048, 24576, 4096, 0), ("down 256", 2048, 4096, 14336, 0),
+              ("s1 qkv", 12736, 6144, 4096, 0), ("s1 gate-up", 12736, 28672, 4096, 3), ("s1 down", 12736, 4096, 14336, 0), ("clip fc1 x64", 36928, 4096, 1024, 1)]
     for name, M, N, K, act in shapes:
         x = torch.rand(M, K, device=dev).bfloat16() * 2 - 1
         ws = [(torch.rand(N, K, device=dev) * 2 - 1).bfloat16() for _ in range(2)]
@@ -214,7 +215,7 @@ def bench_gemm_square():
             tf = 2.0 * M * N * K / us / 1e6
             row.append(f"{'128' if impl == 0 else ('256sk' if ring else '256')}: {us:8.1f} us {tf:7.1f} TF")
         B.check(B.lib().vz_tune_set(4, 1))
-        us = min(timed(lambda i: B.linear(x, ws[i % 3], act=act), 12) for _ in range(3))
+        us = min(timed(lambda i: B.linear(x, ws[i % 2], act=act), 12) for _ in range(3))
         row.append(f"dispatch: {us:8.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF")
         print(f"gemm {name:12s} M{M} N{N} K{K}: " + "   ".join(row), flush=True)
         del ws
@@ -267,6 +268,8 @@ def bench_attn():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
+    for kv in filter(None, os.environ.get("VZ_TUNE", "").split(",")):       # experiments: "knob=value,..." for vz_tune_set
+        B.check(B.lib().vz_tune_set(*(int(v) for v in kv.split("="))))
     if what in ("gemv", "all"):
         bench_gemv()
     if what in ("gemm", "all"):

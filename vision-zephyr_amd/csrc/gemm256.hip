@@ -57,6 +57,7 @@ struct Gemm256Params {
     // stream-K: workgroups [0, n_full) run tiles [0, n_full) whole; the n_rem * nk K-tiles ("units") of the remaining
     // tiles are cut into sk_wgs ranges of units_per_wg
     int n_full, n_rem, sk_wgs, units_per_wg, sk_skew;
+    int n_pers;              // workgroups that run the n_full whole tiles: n_full (one tile each) or fewer (persistent: tile b, b + n_pers, ... ; round 3)
     float* ws; int* tickets;
     int* err;                // async error word: a bounded wait of the stream-K fix-up that expired raises VZ_ASYNC_STREAMK here
     long long* stamps;   // profiling only (vz_tune_set(6, 1)): s_memrealtime at phase boundaries, 16 per workgroup
@@ -308,14 +309,15 @@ __device__ __forceinline__ void gemm256_body(Gemm256Params p) {
 
     // ---- work: one whole tile, or a range of K-tile units of the remainder tiles ----
     const int bid = blockIdx.x;
-    const bool sk = bid >= p.n_full;
+    const bool sk = bid >= p.n_pers;
     int u = 0, u_end = nk, tile = 0, jwg = 0;
+    int t_lin = bid;                    // whole tiles of this workgroup: t_lin, t_lin + n_pers, ... < n_full
     if (!sk) {
-        tile = xcd_order(bid, p.n_full);
+        tile = xcd_order(t_lin, p.n_full);
     } else {
         // range of workgroup j: [j*U + skew(j), (j+1)*U + skew(j+1)), skew = sk_skew for odd j.  Even workgroups get 2*skew
         // K-tiles more than odd ones, so of two slices of a tile one is parked well before the other arrives.
-        jwg = xcd_order(bid - p.n_full, p.sk_wgs);
+        jwg = xcd_order(bid - p.n_pers, p.sk_wgs);
         const int total = p.n_rem * nk;
         u = jwg * p.units_per_wg + ((jwg & 1) ? p.sk_skew : 0);
         u_end = jwg + 1 == p.sk_wgs ? total : (jwg + 1) * p.units_per_wg + ((jwg & 1) ? 0 : p.sk_skew);
@@ -353,21 +355,24 @@ __device__ __forceinline__ void gemm256_body(Gemm256Params p) {
 
         // ---- staging sources: half-tile X_h, instruction j -> LDS chunk ch = j*512 + tid (row ch>>3, slot ch&7) ----
         const char* src[4][2];   // [A_0, A_1, B_0, B_1][j]
+        auto tile_srcs = [&](int bm_, int bn_, int k0_, const char* (&out)[4][2]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ch = j * 512 + tid;
-            const int r = ch >> 3, c = ch & 7;
-            const int gc = (c ^ (r & 7)) * 16 + k0 * 128;
+            for (int j = 0; j < 2; ++j) {
+                const int ch = j * 512 + tid;
+                const int r = ch >> 3, c = ch & 7;
+                const int gc = (c ^ (r & 7)) * 16 + k0_ * 128;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                int arow = bm * 256 + (r >> 6) * 128 + h * 64 + (r & 63);     // LDS row r of A_h <-> wave row wm = r>>6
-                arow = arow < p.M ? arow : p.M - 1;
-                int wrow = bn * 256 + (r >> 5) * 64 + h * 32 + (r & 31);      // LDS row r of B_h <-> wave col wn = r>>5
-                wrow = wrow < p.N ? wrow : p.N - 1;
-                src[h][j] = (const char*)p.A + (size_t)arow * p.lda * ESZ + gc;
-                src[2 + h][j] = (const char*)p.W + (size_t)wrow * p.ldw * ESZ + gc;
+                for (int h = 0; h < 2; ++h) {
+                    int arow = bm_ * 256 + (r >> 6) * 128 + h * 64 + (r & 63);     // LDS row r of A_h <-> wave row wm = r>>6
+                    arow = arow < p.M ? arow : p.M - 1;
+                    int wrow = bn_ * 256 + (r >> 5) * 64 + h * 32 + (r & 31);      // LDS row r of B_h <-> wave col wn = r>>5
+                    wrow = wrow < p.N ? wrow : p.N - 1;
+                    out[h][j] = (const char*)p.A + (size_t)arow * p.lda * ESZ + gc;
+                    out[2 + h][j] = (const char*)p.W + (size_t)wrow * p.ldw * ESZ + gc;
+                }
             }
-        }
+        };
+        tile_srcs(bm, bn, k0, src);
         // region: 0 A_0, 1 A_1, 2 B_0, 3 B_1
         auto stage_at = [&](int region, int kt, int slot_off) {
             const int t = kt < nks ? kt : nks - 1;
@@ -610,7 +615,12 @@ __device__ __forceinline__ void gemm256_body(Gemm256Params p) {
         }
         ++seg_no;
         u += nks;
-        if (u < u_end) __syncthreads();     // next slice re-stages the ring from slot 0
+        if (!sk && u >= u_end && t_lin + p.n_pers < p.n_full) {     // persistent: this workgroup's next whole tile
+            t_lin += p.n_pers;
+            tile = xcd_order(t_lin, p.n_full);
+            u = 0;
+        }
+        if (u < u_end) __syncthreads();     // next slice / next tile re-stages the ring from slot 0
     }
 }
 
@@ -654,6 +664,7 @@ int sk_state_for(hipStream_t s, SkState** out) {
 int g_gemm256_streamk = 1;   // vz_tune_set(4, v): 1 = stream-K tail (default), 0 = whole tiles only
 int g_gemm256_stamps = 0;    // vz_tune_set(6, v): 1 = record in-kernel phase stamps (vz_prof_gemm_stamps)
 int g_gemm256_drain = 0;     // vz_tune_set(11, v)
+int g_gemm256_persist = 1;   // vz_tune_set(34, v)
 int g_gemm256_skew = 2;      // vz_tune_set(5, v): K-tiles by which even / odd stream-K workgroups lead / lag
 
 int vz_init_gemm256_kernel() {
@@ -696,13 +707,19 @@ static int plan_and_launch(Gemm256Params& p, int nk, int* err_word, bool fp8, hi
             }
         }
     }
+    // persistent whole tiles (round 3; vz_tune_set(34, 0) = one workgroup per tile again): with more whole tiles than CUs, P workgroups walk them
+    // (tile b, b + P, ...) instead of n_full workgroups taking one each - no workgroup start / LDS allocation / teardown per tile.  Measured in one
+    // process (tools/bench_kernels.py gemmsq): Stage-1 gate|up (12736 rows, 5600 tiles) 2344 -> 2240 us, Stage-1 QKV 509 -> 496, CLIP fc1 at 64 x 577 rows
+    // 392 -> 376, 4 rounds of Zephyr tiles 446 -> 432; one-round shapes unchanged.  Also built: requesting the NEXT tile's first two K-tiles before the
+    // current tile's epilogue (their HBM latency under the store drain) - no gain over plain persistence (2261 / 503 / 382 / 446 us): removed.
+    p.n_pers = (g_gemm256_persist && p.n_full > P) ? P : p.n_full;
     p.stamps = nullptr; p.drain = g_gemm256_drain;
-    if (g_gemm256_stamps && p.n_full + p.sk_wgs <= 4096) {
-        p.stamps = g_stamps; g_stamp_wgs = p.n_full + p.sk_wgs;
+    if (g_gemm256_stamps && p.n_pers + p.sk_wgs <= 4096) {
+        p.stamps = g_stamps; g_stamp_wgs = p.n_pers + p.sk_wgs;
         VZ_CHECK_HIP(hipMemsetAsync(g_stamps, 0, (size_t)g_stamp_wgs * 16 * sizeof(long long), s));
     }
-    if (fp8) vz_launch_timed(gemm256_fp8_kernel, dim3(p.n_full + p.sk_wgs), dim3(512), RING_BYTES, s, p);
-    else vz_launch_timed(gemm256_bf16_kernel, dim3(p.n_full + p.sk_wgs), dim3(512), RING_BYTES, s, p);
+    if (fp8) vz_launch_timed(gemm256_fp8_kernel, dim3(p.n_pers + p.sk_wgs), dim3(512), RING_BYTES, s, p);
+    else vz_launch_timed(gemm256_bf16_kernel, dim3(p.n_pers + p.sk_wgs), dim3(512), RING_BYTES, s, p);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }
