@@ -757,6 +757,37 @@ def test_attention_shape_fuzz(B, case):
 # ---------------------------------------------------------------------------------------------------------------------
 # stream-K state is per (device, stream); an expired fix-up wait raises the async error word and poisons its tile
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,act", [(8192, 4096, 512, 0), (2048, 28672, 1024, 3), (5000, 6144, 768, 1), (12736, 4096, 256, 0)])
+def test_gemm256_persistent_tiles_equal_one_workgroup_per_tile(B, M, N, K, act):
+    """Round 3: with more whole tiles than CUs, 256 workgroups walk the tiles (tile b, b + 256, ...) instead of one workgroup each
+    (gemm256.hip::plan_and_launch, vz_tune_set(34, 0) = off).  Same tile arithmetic, same stream-K tail: bit-identical outputs - with bias,
+    residual and the fused activations, a partial last row tile (M = 5000) and a stream-K remainder (896 tiles = 3.5 rounds)."""
+    x = _rand((M, K), 1.0, 310).bfloat16()
+    w = _rand((N, K), 0.03, 311).bfloat16()
+    n_out = N // 2 if act == 3 else N
+    bias = _rand((N,), 0.3, 312) if act != 3 else None
+    res = _rand((M, n_out), 1.0, 313).bfloat16()
+    outs = []
+    for knob in (1, 0):
+        try:
+            B.check(B.lib().vz_tune_set(34, knob))
+            outs.append(B.linear(x, w, bias=bias, residual=res, act=act, impl=2))
+        finally:
+            B.check(B.lib().vz_tune_set(34, 1))
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
+    ref = x.float() @ w.float().t()
+    if act == 3:
+        r = ref.view(M, -1, 2, 16)
+        ref = (torch.nn.functional.silu(r[:, :, 0]) * r[:, :, 1]).reshape(M, n_out)
+    else:
+        ref = ref + bias
+        if act == 1:
+            ref = ref * torch.sigmoid(1.702 * ref)
+    ref = ref + res.float()
+    check_close(f"persistent gemm256 {M}x{N}x{K}", outs[0], ref, 2e-2, 6e-3)
+
+
 def test_gemm256_streamk_two_streams_do_not_share_tickets(B):
     """Round 1 kept ONE process-wide set of stream-K slots / tickets: two streams (or two engines) running stream-K GEMMs at the
     same time met on it.  Now every (device, stream) has its own: interleaved launches on two streams give the results of
