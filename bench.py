@@ -464,6 +464,64 @@ def main():
                                        "per_token_ms": round(ms_d / 8, 4)},
                 "decode_allreduce_kernel": "one-shot (csrc/comm_oneshot.hip, VZ_TP_ONESHOT=1)" if getattr(eng, "oneshot", False) else "RCCL ncclAllReduce",
                 "method": "HIP events around every collective of one prefill and 8 eager decode steps after the timed region (rank 0)"}
+        # ---- probe (never `value`): the same decode steps with the decode all-reduces on the hand-written one-shot kernel (csrc/comm_oneshot.hip,
+        # peer areas mapped through hipIpc) - no multi-GPU box was available to the build, so a run on real xGMI is the first measurement of it.
+        # Bounded: ONE eager step first (an absent peer costs a bounded sweep per all-reduce and raises the async word), every rank agrees on
+        # the outcome through a MAX all-reduce before anything longer runs; a failure switches the engine back to RCCL and is reported. ----
+        if rank == 0:
+            # the leg's numbers go out BEFORE the probe: if the probe ever stalls the child into its time limit, the parent still has them
+            print(json.dumps({"early": True, "value": round((n_new - 1) * args.steps / dec_sum, 2), "unit": "tokens/s",
+                              "image_to_first_token_ms": round(ttft_sum / args.steps * 1e3, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+                              "scaling": "strong", "xgmi": xgmi,
+                              "config": {"parallelism": f"tp{world} + tile-dp{world}: one request, Zephyr tensor-parallel + tiles dealt over the group, RCCL over xGMI"}}),
+                  flush=True)
+        if os.environ.get("VZ_BENCH_ONESHOT_PROBE", "1") != "0" and not getattr(eng, "oneshot", False):
+            probe = {"ok": False}
+            try:
+                import ctypes as C
+                mapped = eng.init_oneshot()
+                if not mapped:
+                    probe["why"] = "a rank could not export / map a receive area (hipIpcGetMemHandle / hipIpcOpenMemHandle)"
+                else:
+                    def _err():
+                        e_ = C.c_int(0)
+                        B.check(eng.lib.vz_engine_async_error(eng.h, C.byref(e_)))
+                        return int(e_.value)
+                    _, last = eng.prefill(emb, [S])
+                    eng.decode_begin(last.argmax(-1).to(torch.int32), [S], [S])
+                    eng.prof_enable(True, B.K_COMM)
+                    _, lg1 = eng.decode_steps(1, return_logits=True)
+                    torch.cuda.synchronize()
+                    n_1, ms_1 = eng.prof_read()
+                    eng.prof_enable(False)
+                    bad = torch.tensor([1.0 if (_err() or not bool(torch.isfinite(lg1).all())) else 0.0], device=device)
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                    if float(bad.item()) > 0:
+                        B.check(B.lib().vz_tune_set(29, 0))          # RCCL again for whatever follows
+                        probe["why"] = "the first one-shot step raised the async error word or produced non-finite logits on some rank"
+                    else:
+                        t0 = time.perf_counter()
+                        tm = {}
+                        out1 = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n_new, eos_token_id=None, pad_token_id=2,
+                                              use_cache=True, timing=tm)
+                        sync()
+                        t_dec = time.perf_counter() - tm["t_first_token"]
+                        B.check(B.lib().vz_tune_set(29, 0))
+                        out0 = model.generate(input_ids=ids, images=[tiles], do_sample=False, max_new_tokens=n_new, eos_token_id=None, pad_token_id=2,
+                                              use_cache=True)
+                        sync()
+                        probe = {"ok": True, "decode_tokens_per_s": round((n_new - 1) / t_dec, 2),
+                                 "first_step_collectives": {"launches": n_1, "avg_us": round(ms_1 / max(1, n_1) * 1e3, 2)},
+                                 "ids_equal_to_rccl": bool(torch.equal(out0, out1)), "async_error_after": _err(),
+                                 "what": "128 greedy tokens of the same request with the 64 decode all-reduces per token on comm_oneshot.hip (8-byte {2 x bf16, tag} granules "
+                                         "stored into every peer's area, rank-order fp32 sum) inside the per-token hipGraph"}
+            except Exception as ex:      # the probe must never cost the leg its numbers
+                probe = {"ok": False, "why": f"{type(ex).__name__}: {ex}"[:300]}
+                try:
+                    B.check(B.lib().vz_tune_set(29, 0))
+                except Exception:
+                    pass
+            xgmi["oneshot_probe"] = probe
 
     # ---- roofline legs: instrumented replays of the same work, HIP events on the launch stream ----
     roof, roof_prefill, parity, stream_leg, persist_leg = None, None, None, None, None
@@ -569,9 +627,15 @@ def main():
                     tp_leg = json.loads(lines[-1])
                 else:
                     tp_leg = {"value": None, "error": f"child rc={r.returncode}: {(r.stderr or '')[-400:]}"}
-        except subprocess.TimeoutExpired:
+        except subprocess.TimeoutExpired as ex:
             if rank == 0:
-                tp_leg = {"value": None, "error": f"tensor-parallel child timed out after {limit} s"}
+                out = ex.stdout.decode() if isinstance(ex.stdout, (bytes, bytearray)) else (ex.stdout or "")
+                lines = [l for l in out.splitlines() if l.startswith("{")]
+                if lines:      # the child's early line (its timed region had finished; it stalled afterwards, e.g. inside the one-shot probe)
+                    tp_leg = json.loads(lines[-1])
+                    tp_leg["note"] = f"child hit its {limit} s limit after printing this line"
+                else:
+                    tp_leg = {"value": None, "error": f"tensor-parallel child timed out after {limit} s"}
         barrier()
     if rank != 0:
         if dist is not None:
