@@ -90,3 +90,17 @@ def test_gradients_against_reference_fixtures(gold):
             mine = grads[k].reshape(-1)[::stride][:4096].double().numpy()
             ref = fx[key].astype(np.float64)
             assert np.abs(mine - ref).max() <= 5e-4 * np.abs(ref).max(), k
+
+
+def test_band_fixture_belongs_to_the_step_fixture():
+    """tests/golden/stage1_step_band.npz (oracle/band_train_step.py: the BF16-policy oracle's per-tensor distance from its own fp32 gradients) was
+    made on the SAME batch and weights as stage1_step.npz: same 165 tensors, the same loss (the reference's, to 1e-5), bands of bf16 size."""
+    import os
+    import numpy as np
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(golden, "stage1_step.npz"), allow_pickle=False)
+    b = np.load(os.path.join(golden, "stage1_step_band.npz"), allow_pickle=False)
+    assert sorted(str(n) for n in b["names"]) == sorted(str(n) for n in g["grad_names"]) and len(b["names"]) == 165
+    assert abs(float(b["loss_fp32"]) - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    assert abs(float(b["loss_bf16"]) - float(g["loss"])) <= 1e-3 * float(g["loss"])
+    assert 5e-3 < float(b["band"].min()) and float(b["band"].max()) < 8e-2
