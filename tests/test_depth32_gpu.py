@@ -76,8 +76,15 @@ def test_case_a_logits_and_ids_at_32_layers(deep):
     want = g["A16.generate.ids"][0].tolist()
     first = next((i for i in range(6) if got[i] != want[i]), -1)
     record("depth32 A generate", got=got, w16_reference=want, fp32_reference=g["A.generate.ids"][0].tolist(), first_divergence=first)
-    assert got[0] == want[0] == int(np.argmax(g["A16.logits.last"]))
-    assert int(lo[0, -1].argmax()) == got[0]
+    assert want[0] == int(np.argmax(g["A16.logits.last"])) and int(lo[0, -1].argmax()) == got[0]
+    if got[0] != want[0]:
+        # near-flat logits of random weights: the first id may leave the reference's only at a near-tie MEASURED on this row (the criterion
+        # of the configs[2] test below): the reference's gap between its choice and ours < 4 x this row's rel-L2 error x rms
+        ref_row = g["A16.logits.last"].astype(np.float64)
+        gap = float(ref_row[want[0]] - ref_row[got[0]])
+        tol = 4.0 * e16 * float(np.sqrt((ref_row ** 2).mean()))
+        record("depth32 A first id near-tie", reference_gap=gap, tolerance=tol)
+        assert gap < tol, f"A: first id {got[0]} vs the W16 reference's {want[0]}: its gap {gap:.3e} exceeds 4 x error x rms = {tol:.3e}"
 
 
 def test_configs1_teacher_forced_decode_at_32_layers(deep):
@@ -246,8 +253,7 @@ def test_configs2_against_the_reference_fixture_at_32_layers(deep):
         assert got[first] == int(hip[first].argmax()), "generate() and the teacher-forced step disagree on the same prefix"
         assert gap < tol, f"greedy ids leave the W16 reference at step {first} where its top-2 gap is {gap:.3e} (tolerance {tol:.3e})"
     record("depth32 configs[2] greedy vs reference", argmax_agree_teacher_forced=agree, of=n, first_divergence=first, near_tie=near, got=got, want=want)
-    assert got[0] == want[0]
-    eng.check_async()
+    eng.check_async()           # (a divergence at step 0 is held to the same near-tie criterion by the block above: `first` = 0)
 
 
 @pytest.mark.parametrize("Bn", [12, 40, 64])

@@ -211,13 +211,39 @@ def test_generate_greedy_matches_oracle_and_reference(env):
     assert got.dtype == torch.long and tuple(got.shape) == (1, n_new)          # new tokens only
     emb = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids, None, None, None, None, [tiles], P=O.BF16)[4]
     ref_ids, ref_logits = O.greedy_generate(cfg, sd, emb, n_new, P=O.BF16, return_logits=True)
-    # a greedy step may legitimately differ only where the oracle's own top-2 margin is inside the bf16 band
+    # a greedy step may legitimately leave the oracle's ids only at a near-tie, and "near" is MEASURED (round 3; it was a hand-picked 2e-3 of
+    # max|logit|): the HIP logits of that step under teacher forcing (equal prefixes up to there) must sit inside the step's own bf16 band, and the
+    # oracle's gap between its choice and the HIP choice must be inside what that step's error can move a logit: gap < 4 x rel-L2 error x rms
+    # (the criterion of tests/test_depth32_gpu.py for the headline request)
     top2 = ref_logits[0].topk(2, dim=-1).values
     margin = (top2[:, 0] - top2[:, 1]) / ref_logits[0].abs().amax(-1)
-    for t in range(n_new):
-        if int(got[0, t]) != int(ref_ids[0, t]):
-            assert float(margin[t]) < 2e-3, f"step {t}: id {int(got[0, t])} vs oracle {int(ref_ids[0, t])}, margin {float(margin[t]):.2e}"
-            break
+    first = next((t for t in range(n_new) if int(got[0, t]) != int(ref_ids[0, t])), -1)
+    if first >= 0:
+        eng = model.engine
+        hip_emb = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [tiles])[4]
+        S0 = hip_emb.shape[1]
+        _, last = eng.prefill(hip_emb, [S0], all_logits=False, last_logits=True)
+        hip_t = last[0].float().cpu()
+        forced = ref_ids[0].to(torch.int32)
+        if first > 0:
+            eng.decode_begin(forced[:1], [S0], [S0])
+            for t in range(1, first + 1):
+                _, lg = eng.decode_steps(1, return_logits=True)
+                hip_t = lg[0, 0].float().cpu()
+                if t < first:
+                    eng.decode_set_row(0, int(forced[t]), S0 + t, S0 + t)
+        ref_t = ref_logits[0, first].float()
+        ext32 = O.prepare_inputs_labels_for_multimodal(cfg, sd, ids, None, None, None, None, [tiles], P=O.FP32)[4]
+        if first > 0:        # the fp32 oracle on the same prefix: prompt + the bf16 oracle's first `first` ids
+            ext32 = torch.cat([ext32, O.embed_tokens(sd, ref_ids[:, :first].long(), O.FP32)], 1)
+        ref32_t = O.llm_forward(cfg, sd, ext32, P=O.FP32)[0][0, -1]
+        band(f"generate A: step {first} logits under teacher forcing", hip_t, ref_t, ref32_t)
+        assert int(hip_t.argmax()) == int(got[0, first]), "generate() and the teacher-forced step disagree on the same prefix"
+        e_t = errs(hip_t, ref_t)[1]
+        gap = float(ref_t[int(ref_ids[0, first])] - ref_t[int(got[0, first])])
+        tol = 4.0 * e_t * float(ref_t.double().pow(2).mean().sqrt())
+        record("generate A near-tie", step=first, oracle_gap=gap, tolerance=tol, step_rel_l2=e_t)
+        assert gap < tol, f"step {first}: id {int(got[0, first])} vs oracle {int(ref_ids[0, first])}: the oracle's gap {gap:.3e} exceeds 4 x error x rms = {tol:.3e}"
     record("generate A", got=got[0].tolist(), oracle_bf16=ref_ids[0].tolist(), reference_fp32=g["A.generate.ids"][0].tolist(),
            min_margin=float(margin.min()))
     # against the reference's own fp32 greedy ids (golden): identical up to the first step whose fp32 top-2 margin
