@@ -12,7 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _model(n_layers, max_ctx, weight_fp8=False):
+def _model(n_layers, max_ctx, weight_fp8=False, max_batch=1):
     from vz_hip import synth
     from vis_zephyr.model import VisZephyrConfig, VisZephyrForCausalLM
     cfg = synth.ArchConfig(n_layers=n_layers)
@@ -22,7 +22,7 @@ def _model(n_layers, max_ctx, weight_fp8=False):
     hf.mm_vision_tower = "openai/clip-vit-large-patch14-336"
     hf.mm_patch_merge_type = "flat"
     hf.mm_hidden_size = 5120
-    return cfg, synth, VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=1, max_ctx=max_ctx, max_tiles=1, max_text=max_ctx, weight_fp8=weight_fp8)
+    return cfg, synth, VisZephyrForCausalLM.from_synthetic(hf, seed=0, max_batch=max_batch, max_ctx=max_ctx, max_tiles=1, max_text=max_ctx, weight_fp8=weight_fp8)
 
 
 def _knob(v):
@@ -163,3 +163,41 @@ def test_fused_attention_o_launch_equals_the_two_launches(small, S):
         assert torch.isfinite(res[fused][1]).all()
         assert torch.equal(res[fused][0], res[0][0]) and torch.equal(res[fused][2], res[0][2]), fused
         assert torch.equal(res[fused][1], res[0][1]), f"knob {fused}, S={S}: max |diff| {float((res[fused][1] - res[0][1]).abs().max()):.3e}"
+
+
+@pytest.fixture(scope="module")
+def small2():
+    cfg, synth, model = _model(2, 2300, max_batch=2)
+    yield cfg, synth, model
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("S,short", [(40, 0), (700, 9), (1900, 300)])
+def test_fused_attention_o_launch_with_two_rows(small2, S, short):
+    """the same launch for a 2-row decode step (the rows' attention workgroups + the O projection's 512 workgroups with both rows' outputs in LDS;
+    rows x context splits <= 32 keeps every workgroup resident): logits and ids of both rows EQUAL the two-launch route's, ragged lengths included"""
+    from vz_hip import binding as B
+    cfg, synth, model = small2
+    eng = model.engine
+    lens = [S, S - short]
+    ids = torch.stack([synth.synth_ids(S, cfg.vocab, image_pos=-1, seed=800 + S + r) for r in range(2)])
+    emb = eng.embed_tokens(ids.reshape(-1)).view(2, S, -1)
+    res = {}
+    for fused in (1, 0):
+        B.check(B.lib().vz_tune_set(30, fused))
+        try:
+            _, last = eng.prefill(emb, lens, all_logits=False, last_logits=True)
+            eng.decode_begin(last.argmax(-1).to(torch.int32), lens, lens)
+            toks, lg = eng.decode_steps(4, return_logits=True)
+            _, last = eng.prefill(emb, lens, all_logits=False, last_logits=True)
+            eng.decode_begin(last.argmax(-1).to(torch.int32), lens, lens)
+            toks_g = eng.decode_steps(9)
+            torch.cuda.synchronize()
+            eng.check_async()
+            res[fused] = (toks.clone(), lg.clone(), toks_g.clone())
+        finally:
+            B.check(B.lib().vz_tune_set(30, 1))
+    assert torch.isfinite(res[1][1]).all()
+    assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][2], res[0][2])
+    assert torch.equal(res[1][1], res[0][1]), f"S={S}: max |diff| {float((res[1][1] - res[0][1]).abs().max()):.3e}"

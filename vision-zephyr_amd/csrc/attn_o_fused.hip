@@ -66,18 +66,19 @@ __device__ __forceinline__ void fp8x16_to_bf16(const u32x4 w, u32x4& lo, u32x4& 
 
 union AoShared {
     Shared attn;
-    struct { __attribute__((aligned(16))) bf16_t att[OH]; int ok; } o;
+    struct { __attribute__((aligned(16))) bf16_t att[2 * OH]; int ok; } o;      // up to two rows' attention outputs
 };
 
-template <bool FP8>
+template <bool FP8, int NB>          // NB = rows of the decode step (1 or 2: the GEMV route's row counts that keep the whole grid resident)
 __global__ __launch_bounds__(256, 3) void attn_o_fused_kernel(AoParams p) {      // 3 waves per SIMD = 3 blocks per CU: <= 168 registers
     __shared__ AoShared sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_attn = p.at.nsplit * p.at.Hkv;
+    const int per_row = p.at.nsplit * p.at.Hkv, n_attn = NB * per_row;
     if ((int)blockIdx.x < n_attn) {
         // ---- attention role ----
-        const int split = blockIdx.x % p.at.nsplit, hk = blockIdx.x / p.at.nsplit;
-        const bool merged = body<true>(p.at, p.at.qkv, split, hk, 0, tid, true, sm.attn);
+        const int b = NB == 1 ? 0 : (int)blockIdx.x / per_row, rem = (int)blockIdx.x - b * per_row;
+        const int split = rem % p.at.nsplit, hk = rem / p.at.nsplit;
+        const bool merged = body<true>(p.at, p.at.qkv + (size_t)b * (p.at.Hq + 2 * p.at.Hkv) * D, split, hk, b, tid, true, sm.attn);
         if (!merged) return;                                   // (uniform per block)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the merged heads' write-through stores have left
         __syncthreads();
@@ -103,8 +104,10 @@ __global__ __launch_bounds__(256, 3) void attn_o_fused_kernel(AoParams p) {     
 #pragma unroll
             for (int c = 0; c < NC; ++c) w[r][c] = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)r * OH + c * 512));
     }
-    const unsigned resid = *(const unsigned*)(p.x + r0);       // x[r0], x[r0 + 1]
-    const unsigned target = ((unsigned)p.step[0] * (unsigned)p.n_layers + (unsigned)p.layer + 1u) * (unsigned)p.at.Hkv;
+    unsigned resid[NB];                                        // x[b][r0], x[b][r0 + 1]
+#pragma unroll
+    for (int b = 0; b < NB; ++b) resid[b] = *(const unsigned*)(p.x + (size_t)b * OH + r0);
+    const unsigned target = ((unsigned)p.step[0] * (unsigned)p.n_layers + (unsigned)p.layer + 1u) * (unsigned)(p.at.Hkv * NB);
     if (wave == 0) {
         int ok = 0;
         for (int it = 0; it < SPIN_CAP; ++it) {
@@ -117,40 +120,53 @@ __global__ __launch_bounds__(256, 3) void attn_o_fused_kernel(AoParams p) {     
     __syncthreads();
     // every merged head is in memory: gather the 4096 outputs (8-byte L2-bypassing loads, all in flight), then the dot products
     {
-        unsigned long long v[4];
+        unsigned long long v[4 * NB];        // (the rows' outputs are contiguous in the hand-off vector: [NB][4096])
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = __hip_atomic_load((const unsigned long long*)(p.at.o + (i * 256 + tid) * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 4 * NB; ++i) v[i] = __hip_atomic_load((const unsigned long long*)(p.at.o + (i * 256 + tid) * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(unsigned long long*)(sm.o.att + (i * 256 + tid) * 4) = v[i];
+        for (int i = 0; i < 4 * NB; ++i) *(unsigned long long*)(sm.o.att + (i * 256 + tid) * 4) = v[i];
     }
     __syncthreads();
-    float acc[2] = {0.f, 0.f};
+    float acc[2][NB];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
     if constexpr (FP8) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {                       // gemv_bf16_kernel<.., FP8>'s chunk order and lane -> k assignment (1024 k per chunk, 16 per lane)
-            const u32x4 x0 = *(const u32x4*)(sm.o.att + c * 1024 + lane * 16), x1 = *(const u32x4*)(sm.o.att + c * 1024 + lane * 16 + 8);
+            u32x4 wl[2], wh[2];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                u32x4 wl, wh;
-                fp8x16_to_bf16(w[r][c], wl, wh);
-                acc[r] = dot8(wh, x1, dot8(wl, x0, acc[r]));
+            for (int r = 0; r < 2; ++r) fp8x16_to_bf16(w[r][c], wl[r], wh[r]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const bf16_t* xp = sm.o.att + b * OH + c * 1024 + lane * 16;
+                const u32x4 x0 = *(const u32x4*)xp, x1 = *(const u32x4*)(xp + 8);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc[r][b] = dot8(wh[r], x1, dot8(wl[r], x0, acc[r][b]));
             }
         }
     } else {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const u32x4 xv = *(const u32x4*)(sm.o.att + c * 512 + lane * 8);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) acc[r] = dot8(w[r][c], xv, acc[r]);
+            for (int b = 0; b < NB; ++b) {
+                const u32x4 xv = *(const u32x4*)(sm.o.att + b * OH + c * 512 + lane * 8);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc[r][b] = dot8(w[r][c], xv, acc[r][b]);
+            }
         }
     }
-    const float s0 = wave_sum_lane63(acc[0]), s1 = wave_sum_lane63(acc[1]);
-    if (lane == 63) {
-        float t0 = s0, t1 = s1;
-        if constexpr (FP8) { t0 *= p.o_scale[r0]; t1 *= p.o_scale[r0 + 1]; }       // the row's power-of-two scale, once per output
-        t0 += bf16_to_f32((unsigned short)(resid & 0xffffu)); t1 += bf16_to_f32((unsigned short)(resid >> 16));
-        if (!sm.o.ok) t0 = t1 = __uint_as_float(0x7fc00000u);          // an expired wait never passes for a result
-        *(unsigned*)(p.x + r0) = pack_bf16x2(t0, t1);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float s0 = wave_sum_lane63(acc[0][b]), s1 = wave_sum_lane63(acc[1][b]);
+        if (lane == 63) {
+            float t0 = s0, t1 = s1;
+            if constexpr (FP8) { t0 *= p.o_scale[r0]; t1 *= p.o_scale[r0 + 1]; }       // the row's power-of-two scale, once per output
+            t0 += bf16_to_f32((unsigned short)(resid[b] & 0xffffu)); t1 += bf16_to_f32((unsigned short)(resid[b] >> 16));
+            if (!sm.o.ok) t0 = t1 = __uint_as_float(0x7fc00000u);          // an expired wait never passes for a result
+            *(unsigned*)(p.x + (size_t)b * OH + r0) = pack_bf16x2(t0, t1);
+        }
     }
 }
 
@@ -159,15 +175,22 @@ __global__ __launch_bounds__(256, 3) void attn_o_fused_kernel(AoParams p) {     
 int g_attn_o_delay = 12;      // vz_tune_set(31, n): the O role waits n x ~0.21 us before requesting its weights, so that the attention blocks' K / V loads reach the memory system first (scan at ctx 2048: 0 -> 344, 8 -> 346, 12 -> 357, 16 -> 352, 24 -> 348 tok/s)
 int vz_launch_attn_o_fused(const AttnDecodeFusedArgs& a, const bf16_t* o_w, const unsigned char* o_w8, const float* o_scale, bf16_t* att_scratch,
                            bf16_t* x, unsigned* done, const int* step, int layer, int n_layers, int* err, hipStream_t s) {
-    VZ_CHECK_ARG(a.B == 1 && a.D == D && a.Hq == 32 && a.Hkv == 8 && a.nsplit >= 1 && a.nsplit <= 32, "attn_o_fused: batch 1, 32 / 8 heads of 128, <= 32 context splits");
+    VZ_CHECK_ARG((a.B == 1 || a.B == 2) && a.D == D && a.Hq == 32 && a.Hkv == 8 && a.nsplit >= 1 && a.B * a.nsplit <= 32,
+                 "attn_o_fused: 1 or 2 rows, 32 / 8 heads of 128, rows x context splits <= 32 (every workgroup resident)");
     VZ_CHECK_ARG(a.qkv && a.kc && a.vc && att_scratch && a.part && a.ticket && (o_w || (o_w8 && o_scale)) && x && done && step && err, "attn_o_fused: null argument");
     AoParams p;
     p.at.qkv = a.qkv; p.at.kc = a.kc; p.at.vc = a.vc; p.at.o = att_scratch; p.at.part = a.part; p.at.ticket = a.ticket;
     p.at.cosT = a.cosT; p.at.sinT = a.sinT; p.at.pos = a.pos; p.at.slot = a.slot;
-    p.at.B = 1; p.at.Hq = a.Hq; p.at.Hkv = a.Hkv; p.at.max_ctx = a.max_ctx; p.at.nsplit = a.nsplit; p.at.window = a.window; p.at.scale = a.scale;
+    p.at.B = a.B; p.at.Hq = a.Hq; p.at.Hkv = a.Hkv; p.at.max_ctx = a.max_ctx; p.at.nsplit = a.nsplit; p.at.window = a.window; p.at.scale = a.scale;
     p.o_w = o_w; p.o_w8 = o_w8; p.o_scale = o_scale; p.x = x; p.done = done; p.step = step; p.err = err; p.layer = layer; p.n_layers = n_layers; p.delay = g_attn_o_delay;
-    if (o_w8 && o_scale) hipLaunchKernelGGL(attn_o_fused_kernel<true>, dim3(a.nsplit * a.Hkv + O_BLOCKS), dim3(256), 0, s, p);      // e4m3 rows take precedence (as in linear())
-    else hipLaunchKernelGGL(attn_o_fused_kernel<false>, dim3(a.nsplit * a.Hkv + O_BLOCKS), dim3(256), 0, s, p);
+    const dim3 grid(a.B * a.nsplit * a.Hkv + O_BLOCKS);
+    if (o_w8 && o_scale) {       // e4m3 rows take precedence (as in linear())
+        if (a.B == 1) hipLaunchKernelGGL((attn_o_fused_kernel<true, 1>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((attn_o_fused_kernel<true, 2>), grid, dim3(256), 0, s, p);
+    } else {
+        if (a.B == 1) hipLaunchKernelGGL((attn_o_fused_kernel<false, 1>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((attn_o_fused_kernel<false, 2>), grid, dim3(256), 0, s, p);
+    }
     VZ_LAUNCH_CHECK();
     return VZ_OK;
 }

@@ -1228,7 +1228,7 @@ static int decode_step_launch(vz_engine* e, int* d_out_ids, int out_stride, floa
         { ProfScope ps(e, K_OTHER, s); RC(vz_launch_embed_tokens(cur, B, H, WB("llm.embed", (long)c.vocab * H), x, s)); }
         for (int i = 0; i < c.n_layers; ++i) {
             const std::string p = "llm." + std::to_string(i) + ".";
-            const bool fuse_ao = g_attn_o && B == 1 && e->tp == 1 && tp_local(e) && H == 4096 && A == 4096 && Hq == 32 && Hkv == 8 &&
+            const bool fuse_ao = g_attn_o && (B == 1 || (B == 2 && g_attn_o >= 1 && 2 * e->dec_nsplit <= 32)) && e->tp == 1 && tp_local(e) && H == 4096 && A == 4096 && Hq == 32 && Hkv == 8 &&
                                  D == 128 && e->dec_nsplit <= 32 && e->d_ao_done;
             RC(linear(e, 1, x, H, WB(p + "qkv.w", (long)QKV * H), H, qkv, QKV, B, QKV, H, nullptr, nullptr, 0, VZ_ACT_NONE, 0, s, WF(p + "in_norm", H), c.rms_eps,
                       W8(p + "qkv.w8", (long)QKV * H), WS(p + "qkv.ws", QKV)));
