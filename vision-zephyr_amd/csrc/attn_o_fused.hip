@@ -1,4 +1,4 @@
-// Decode attention + O projection of a batch-1 step in ONE launch (gfx950).
+// Decode attention + O projection of a 1- or 2-row step in ONE launch (gfx950).
 //
 // In the launch chain the O projection's GEMV (33.5 MB of weights, ~8 us) starts after the attention kernel (~12.8 us at ctx 2048, a chain
 // of dependent round trips during which HBM is nearly idle) has ended: 20.8 us for 42 MB.  A weight never depends on the token, so here
@@ -13,6 +13,8 @@
 // once, so a waiting block can only wait for blocks that are running (no order or placement is assumed; the wait is bounded anyway:
 // an expired one raises the async error word).  The arrival word is monotonic within a vz_llm_decode_steps call
 // (target = (step * layers + layer + 1) * Hkv) and zeroed by the host with the step counter.
+// Two rows (NB = 2): the rows' attention workgroups side by side (rows x splits <= 32), both rows' outputs gathered, 2 x 2 dot products per wave:
+// 3.11 -> 2.99 ms per 2-row step.
 // Measured (bench.py's request, ctx 2048): 357 tok/s against 340 for the two launches (attention 12.6 us + O GEMV 8.5 us -> 19.4 us for
 // the fused launch).  Also built and measured this round, and removed again: the RMSNorm + QKV projection as a THIRD role in front
 // (QKV role one block per CU, the cached K / V requested before QKV had finished, the O role waiting for QKV before it streams): bit-identical,
