@@ -63,7 +63,7 @@ def deep64_fp8():
     from vz_hip import synth
     from vis_zephyr.model import VisZephyrForCausalLM
     cfg = synth.ArchConfig(n_layers=32)
-    model = VisZephyrForCausalLM.from_synthetic(_hf(cfg), seed=0, max_batch=64, max_ctx=200 + 4 * 32 + 128 + 16, max_tiles=64, max_text=208,
+    model = VisZephyrForCausalLM.from_synthetic(_hf(cfg), seed=0, max_batch=64, max_ctx=200 + 4 * 32 + 128 + 16, max_tiles=64, max_text=336,
                                                 weight_fp8=True)
     yield dict(cfg=cfg, model=model, synth=synth)
     del model

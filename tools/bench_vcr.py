@@ -41,7 +41,11 @@ rng = np.random.default_rng(0)
 frames = [torch.from_numpy(rng.integers(0, 256, (804, 1920, 3), dtype=np.uint8)) for _ in range(MAXB)]     # host memory, as a loader hands them over
 prompts = [synth.synth_ids(L_PROMPT, 32000, image_pos=5, seed=100 + i) for i in range(MAXB)]
 
-for B in (() if "stream" in sys.argv[1:] else (1, 4, 8, 16, 32, 64)):
+for kv in filter(None, os.environ.get("VZ_TUNE", "").split(",")):       # experiments: "knob=value,..." for vz_tune_set
+    from vz_hip import binding as _B
+    _B.check(_B.lib().vz_tune_set(*(int(v) for v in kv.split("="))))
+ROWS = tuple(int(v) for v in os.environ.get("VZ_ROWS", "1,4,8,16,32,64").split(","))
+for B in (() if "stream" in sys.argv[1:] else ROWS):
     def run():
         t0 = time.perf_counter()
         tiles = [pre(f, PINS) for f in frames[:B]]                          # H2D + LANCZOS + tiling + normalise on the device

@@ -213,6 +213,29 @@ __device__ __forceinline__ bool body(const FusedParams& p, const bf16_t* row, in
         }
     }
     __syncthreads();
+    if (n_active == 1) {
+        // ONE split covers the row's whole context (short contexts; wide batches, whose rows fill the chip by themselves): nothing to meet -
+        // no partial record, no ticket, no re-read.  The merge below with a single partial multiplies by exp(0) = 1 and divides by the same
+        // l: these are the same bits.
+        if (act) {
+            for (int i = tid; i < G * D; i += 256) {
+                const int h = i >> 7, d = i & 127;
+                float v = 0.f;
+#pragma unroll
+                for (int s16 = 0; s16 < 16; ++s16) v += sm.red[s16][h][d];
+                const float l = sm.stat[2 * G + h];
+                const unsigned short ob = f32_to_bf16(v * (l > 0.f ? 1.0f / l : 0.f));
+                bf16_t* dst = p.o + ((size_t)b * p.Hq + hk * G) * D + i;
+                if (OUT_SC1) {
+                    const unsigned other = __shfl_xor((unsigned)ob, 1, 64);
+                    if ((lane & 1) == 0) __hip_atomic_store((unsigned*)dst, (unsigned)ob | (other << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    *dst = ob;
+                }
+            }
+        }
+        return true;
+    }
     float* po = p.part + (((size_t)b * p.Hkv + hk) * p.nsplit + split) * PW;
     if (act) {
         for (int i = tid; i < G * D; i += 256) {
@@ -284,6 +307,7 @@ __device__ __forceinline__ void shadow(const FusedParams& p, int split, int slot
         __syncthreads();                   // P V
     }
     __syncthreads();                       // key-slot partials in LDS
+    if (n_active == 1) return;             // (the direct path: no record, no ticket)
     __syncthreads();                       // partial record stored
     __syncthreads();                       // ticket taken
     if (!sm.last_flag) return;

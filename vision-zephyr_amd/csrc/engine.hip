@@ -1383,6 +1383,10 @@ extern "C" int vz_llm_decode_steps(vz_engine* e, int n, int* d_out_ids, float* d
         static const int buckets[] = {1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 24, 28, 32};
         int ns = e->nsplit;
         for (int bk : buckets) if (bk >= need) { ns = std::min(bk, e->nsplit); break; }
+        // many rows fill the chip by themselves: splitting their contexts as well only adds dispatch slots and a merge hop per (row, KV head)
+        // (config-5 miniature, e4m3, ctx ~330: 64 rows x 3 splits -> x 1: decode 627 -> 597 ms per batch; 32 rows x 3 -> x 2: 459 -> 448) -
+        // rows x KV heads x splits is held to ~512 workgroups; 1..2 rows keep every split (batch-1 numbers unchanged)
+        ns = std::min(ns, std::max(1, 512 / std::max(1, B * e->Hkv_l)));
         e->dec_nsplit = g_attn_nsplit > 0 ? g_attn_nsplit : ns;
         for (int b = 0; b < B; ++b) {       // what the device-side state will be after these n steps (the tail saturates, so do we)
             if (e->h_parked[b]) { e->h_len[b] = std::min(e->h_len[b] + n, c.max_ctx); e->h_pos[b] = std::min(e->h_pos[b] + n, e->rope_max - 1); }
