@@ -70,13 +70,15 @@ __device__ __forceinline__ bool body(const FusedParams& p, const bf16_t* row, in
     // ---- the first chunk's K and V rows go in flight before anything else (the new token's row, index `slot`,
     //      is not in the cache yet: it is patched in from LDS after the RoPE) ----
     uint4 kreg[NR], vreg[NR];
-    auto issue = [&](int c0, int n) {
+    auto issue_k = [&](int c0, int n) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int kk = ks + 16 * i, kidx = c0 + kk;
             kreg[i] = make_uint4(0, 0, 0, 0);
             if (act && kk < n && kidx != slot) kreg[i] = *(const uint4*)(kb + (size_t)kidx * D + sub * 8);
         }
+    };
+    auto issue_v = [&](int c0, int n) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int kk = ks + 16 * i, kidx = c0 + kk;
@@ -84,7 +86,7 @@ __device__ __forceinline__ bool body(const FusedParams& p, const bf16_t* row, in
             if (act && kk < n && kidx != slot) vreg[i] = *(const uint4*)(vb + (size_t)kidx * D + sub * 8);
         }
     };
-    if (k0 < k1) issue(k0, min(CH, k1 - k0));
+    if (k0 < k1) { issue_k(k0, min(CH, k1 - k0)); issue_v(k0, min(CH, k1 - k0)); }
 
     // ---- RoPE: thread (h = wave, pair = lane) rotates (d, d+64) of query head hk*G + h ----
     if (act) {
@@ -121,7 +123,9 @@ __device__ __forceinline__ bool body(const FusedParams& p, const bf16_t* row, in
 
     for (int c0 = k0; c0 < k1; c0 += CH) {
         const int n = min(CH, k1 - c0);
-        if (c0 != k0) issue(c0, n);
+        // (a split of several chunks - many rows, one split per context: the NEXT chunk's K rows are requested as soon as this chunk's scores have
+        // consumed theirs, its V rows after this chunk's P V: the loads pass under the softmax / P V / next scores instead of heading each chunk)
+        const int c1 = c0 + CH, n1 = min(CH, k1 - c1);
         if (act) {
             if (slot >= c0 && slot < c0 + n && ((slot - c0) & 15) == ks) {   // this lane group holds the new token's row
                 const int i_new = (slot - c0) >> 4;
@@ -161,6 +165,7 @@ __device__ __forceinline__ bool body(const FusedParams& p, const bf16_t* row, in
                 }
             }
         }
+        if (c1 < k1) issue_k(c1, n1);
         __syncthreads();
         // ---- online softmax, wave h owns head h ----
         if (act) {
@@ -202,6 +207,7 @@ __device__ __forceinline__ bool body(const FusedParams& p, const bf16_t* row, in
                 }
             }
         }
+        if (c1 < k1) issue_v(c1, n1);
         __syncthreads();   // sc / stat are rewritten by the next chunk
     }
     // ---- reduce the 16 key slots through LDS, write this split's partial (write-through stores) ----
