@@ -156,8 +156,11 @@ __device__ __forceinline__ bool body(const FusedParams& p, const bf16_t* row, in
                 }
 #pragma unroll
                 for (int h = 0; h < G; ++h) {
-                    s[h] += __shfl_xor(s[h], 1, 64); s[h] += __shfl_xor(s[h], 2, 64);
-                    s[h] += __shfl_xor(s[h], 4, 64); s[h] += __shfl_xor(s[h], 8, 64);
+                    // the 16 lanes of a row hold the 16 d-chunks of one key: row-wide sum by four DPP adds on the VALU (quad swaps, half-row mirror,
+                    // row mirror; every lane ends with the row's sum).  The xor butterfly compiled to 128 ds_bpermute_b32 per thread and chunk -
+                    // four dependent round trips through the LDS pipeline per (key, head)
+                    s[h] = dpp_add<0xb1, 0xf>(s[h]); s[h] = dpp_add<0x4e, 0xf>(s[h]);
+                    s[h] = dpp_add<0x141, 0xf>(s[h]); s[h] = dpp_add<0x140, 0xf>(s[h]);
                 }
                 if (sub == 0 && kk < n) {
 #pragma unroll
