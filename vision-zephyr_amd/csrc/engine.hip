@@ -1489,6 +1489,7 @@ extern "C" int vz_test_corrupt_streamk(vz_stream stream, int tile, int arrive, i
 }
 
 extern int g_attn_o_delay;
+extern int g_skinny_even;
 extern int g_gemm256_streamk, g_gemm256_skew, g_gemm256_stamps, g_gemm256_drain, g_gemm256_persist, g_attn_stamp_on, g_fp8_gemm_choice;
 int vz_gemm256_read_stamps(long long* host, int max_wgs, int* n_wgs);
 extern "C" int vz_tune_set(int knob, int value) {
@@ -1517,6 +1518,7 @@ extern "C" int vz_tune_set(int knob, int value) {
     if (knob == 32) { g_flash_bwd = value; return VZ_OK; }
     if (knob == 33) { g_rope_in_attn = value; return VZ_OK; }
     if (knob == 34) { g_gemm256_persist = value; return VZ_OK; }
+    if (knob == 35) { g_skinny_even = value; return VZ_OK; }
     if (knob == 26) { vz_set_splitk_mid(value); return VZ_OK; }
     if (knob == 15) { g_decode_sk_short = value; return VZ_OK; }
     if (knob == 16) { g_attn_stamp_on = value; return VZ_OK; }

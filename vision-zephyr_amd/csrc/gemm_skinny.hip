@@ -20,6 +20,7 @@
 //     fragments in registers (exact) and the row's power-of-two scale multiplies the fp32 result once.
 #include "vz_common.h"
 
+int g_skinny_even = 1;          // vz_tune_set(35, 0): one persistent workgroup per CU whatever the group count (A/B)
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -530,7 +531,11 @@ int launch_persist(const SkinnyParams& p, int n_groups, size_t lds, hipStream_t 
     // against 3.98 / 4.03 / 4.08 with two (knob 9 = 4) - the eight waves' synchronised bursts again
     const int per_cu = g_skinny_mode == 4 ? ((160 * 1024) / (int)lds >= 2 ? 2 : 1) : 1;
     const int cap = g_num_cu_skinny * per_cu;
-    const int grid = n_groups < cap ? n_groups : cap;
+    // the launch lasts as long as its busiest workgroup: ceil(n_groups / cap) groups.  With that many groups on EVERY workgroup fewer of them
+    // are needed (QKV: 384 groups = 2 per workgroup on 192 CUs instead of 2 on 128 + 1 on 128; the waves' bursts then share HBM with fewer
+    // others): same summation per group, bit-identical
+    const int rounds = (n_groups + cap - 1) / cap;
+    const int grid = g_skinny_even ? (n_groups + rounds - 1) / rounds : (n_groups < cap ? n_groups : cap);
     vz_launch_timed(skinny_persist_kernel<SWIGLU, FP8>, dim3(grid), dim3(512), lds, s, p, n_groups);
     VZ_LAUNCH_CHECK();
     return VZ_OK;
