@@ -434,7 +434,8 @@ int vz_op_argmax(const float* d_logits, int rows, int cols, int* d_ids, vz_strea
  *  29  one-shot all-reduce for the TP decode step when peer areas are attached [1]   30  batch-1 decode attention + O projection as one launch (attn_o_fused.hip) [1]
  *  31  that launch's O role: wait (x ~0.2 us) before it requests its weights [12]    32  training step: tile-resident attention backward for head_dim 128 [1]
  *  33  prefill: RoPE of the queries inside the attention's Q load [1; 0 = a rotated copy of Q from rope_kv_kernel; bit-identical]
- *  34  256^2 GEMM: persistent whole-tile workgroups when a launch has more whole tiles than CUs [1; 0 = one workgroup per tile; bit-identical] */
+ *  34  256^2 GEMM: persistent whole-tile workgroups when a launch has more whole tiles than CUs [1; 0 = one workgroup per tile; bit-identical]
+ *  35  3..16-row persistent weight stream: the same number of row groups on every workgroup [1; 0 = one workgroup per CU; bit-identical] */
 int vz_tune_set(int knob, int value);
 
 /* per-kernel-class timing of the engine's launches with HIP events on the launch stream (bench.py's roofline
